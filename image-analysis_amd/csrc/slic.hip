@@ -1,0 +1,621 @@
+// SLIC superpixels for gfx950 -- replaces SLICSuperPixel.run() (scripts/slic.py:35-127).
+//
+// Reference semantics kept:
+//   * centre order column-major (ix*ny + iy); 3x3 gradient nudge with first-minimum wins;
+//   * num_iter-1 rounds; distance reset every round, labels persist;
+//   * colour distance to the IMAGE PIXEL at the centre position, not to the mean colour;
+//   * windows [c-S, c+S) clamped, last row / column never labelled;
+//   * ties go to the lowest centre index; centres are floor(sum / count), empty -> 0.
+//
+// Data flow per round (all state in the caller's workspace, nothing allocated here):
+//   bin:     centres -> S x S cell lists (count / scan / fill) + colour at the centre position
+//   assign:  one workgroup per 64 x 16 pixel tile.  The centres whose window can reach the
+//            tile are gathered into LDS (sorted by index, so "first strictly smaller wins"
+//            is exactly the reference's sequential sweep), every lane evaluates its 4 pixels
+//            against them with an exact integer key
+//                 key = dc^2 * S^2 + ds^2 * cw^2        (same order as slic.py:101-109)
+//            and the per-label sums of slic.py:118-125 are accumulated in lane-private LDS
+//            slots (conflict-free ds_add), reduced once per tile and flushed with one 64-bit
+//            global atomic per (tile, centre, field).  Integer sums => bit-reproducible.
+//   finalise: centre = floor(sum / count).
+//
+// HBM traffic per round: 3 B/px read (u8 Lab) + 4 B/px written (int32 labels).
+#include "common.h"
+#include "../../include/imgan.h"
+#include <math.h>
+
+namespace {
+
+constexpr int TW = 64;      // tile width  (16 lanes x 4 pixels)
+constexpr int TH = 16;      // tile height (4 waves x 4 rows)
+constexpr int MAXC = 40;    // centres per tile handled by the LDS fast path
+constexpr int NFIELD = 6;   // sum L, a, b, x, y, count
+
+struct Layout {
+    int ncx, ncy, ncell;
+    size_t off_count, off_start, off_fill, off_items, off_cand, off_sums, total;
+};
+
+Layout make_layout(int B, int H, int W, int S, int n) {
+    Layout L;
+    L.ncx = (W + S - 1) / S;
+    L.ncy = (H + S - 1) / S;
+    L.ncell = L.ncx * L.ncy;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o = imgan::align_up(o + bytes, 256);
+        return at;
+    };
+    L.off_count = take((size_t)B * L.ncell * 4);
+    L.off_fill = take((size_t)B * L.ncell * 4);
+    L.off_start = take((size_t)B * (L.ncell + 1) * 4);
+    L.off_items = take((size_t)B * n * 4);
+    L.off_cand = take((size_t)B * n * 16);
+    L.off_sums = take((size_t)B * n * NFIELD * 8);
+    L.total = o;
+    return L;
+}
+
+struct Ws {
+    int* count;
+    int* fill;
+    int* start;
+    int* items;
+    int4* cand;             // cx, cy, packed Lab (L | a<<8 | b<<16), cell
+    unsigned long long* sums;
+    int ncx, ncy, ncell;
+};
+
+Ws bind(void* ws, const Layout& L) {
+    char* p = (char*)ws;
+    Ws w;
+    w.count = (int*)(p + L.off_count);
+    w.fill = (int*)(p + L.off_fill);
+    w.start = (int*)(p + L.off_start);
+    w.items = (int*)(p + L.off_items);
+    w.cand = (int4*)(p + L.off_cand);
+    w.sums = (unsigned long long*)(p + L.off_sums);
+    w.ncx = L.ncx;
+    w.ncy = L.ncy;
+    w.ncell = L.ncell;
+    return w;
+}
+
+// ------------------------------------------------------------------ init (slic.py:35-76)
+__global__ void slic_init_kernel(const uint8_t* __restrict__ lab, int32_t* __restrict__ centres,
+                                 int B, int H, int W, int S, int nx, int ny) {
+    int n = nx * ny;
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n) return;
+    int b = t / n, c = t - b * n;
+    int ix = c / ny, iy = c - ix * ny;
+    int sx = S + ix * S, sy = S + iy * S;
+    const uint8_t* img = lab + (size_t)b * H * W * 3;
+    int best = 0x7fffffff, bx = sx, by = sy;
+    for (int i = sx - 1; i <= sx + 1; ++i)
+        for (int j = sy - 1; j <= sy + 1; ++j) {
+            int l1 = img[((size_t)(j + 1) * W + i) * 3];
+            int l2 = img[((size_t)j * W + i + 1) * 3];
+            int l3 = img[((size_t)j * W + i) * 3];
+            int g = abs(l1 - l3) + abs(l2 - l3);
+            if (g < best) {
+                best = g;
+                bx = i;
+                by = j;
+            }
+        }
+    const uint8_t* px = img + ((size_t)by * W + bx) * 3;
+    int32_t* o = centres + (size_t)t * 5;
+    o[0] = px[0];
+    o[1] = px[1];
+    o[2] = px[2];
+    o[3] = bx;
+    o[4] = by;
+}
+
+// ------------------------------------------------------------------ binning
+__global__ void slic_prepare_kernel(const uint8_t* __restrict__ lab,
+                                    const int32_t* __restrict__ centres, Ws w, int B, int H, int W,
+                                    int S, int n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n) return;
+    int b = t / n;
+    const int32_t* c = centres + (size_t)t * 5;
+    int cx = min(max(c[3], 0), W - 1), cy = min(max(c[4], 0), H - 1);
+    const uint8_t* px = lab + (((size_t)b * H + cy) * W + cx) * 3;
+    int packed = px[0] | (px[1] << 8) | (px[2] << 16);
+    int cell = (cy / S) * w.ncx + (cx / S);
+    w.cand[t] = make_int4(cx, cy, packed, cell);
+    atomicAdd(&w.count[(size_t)b * w.ncell + cell], 1);
+    unsigned long long* s = w.sums + (size_t)t * NFIELD;
+#pragma unroll
+    for (int k = 0; k < NFIELD; ++k) s[k] = 0ull;
+}
+
+// one workgroup per image: exclusive scan of the cell counts
+__global__ __launch_bounds__(1024) void slic_scan_kernel(Ws w) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    int b = blockIdx.x;
+    const int* cnt = w.count + (size_t)b * w.ncell;
+    int* start = w.start + (size_t)b * (w.ncell + 1);
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < w.ncell; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = (i < w.ncell) ? cnt[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int add = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        int incl = part[threadIdx.x];
+        if (i < w.ncell) start[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) start[w.ncell] = carry;
+}
+
+__global__ void slic_fill_kernel(Ws w, int B, int n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n) return;
+    int b = t / n, c = t - b * n;
+    int cell = w.cand[t].w;
+    int pos = w.start[(size_t)b * (w.ncell + 1) + cell] +
+              atomicAdd(&w.fill[(size_t)b * w.ncell + cell], 1);
+    w.items[(size_t)b * n + pos] = c;
+}
+
+// ------------------------------------------------------------------ assignment
+struct __attribute__((packed, aligned(4))) Dword3 {
+    uint32_t a, b, c;
+};
+
+struct AssignParams {
+    int B, H, W, S, n;
+    unsigned S2, cw2;         // integer key weights (modes 0, 1)
+    double S2d, cw2d;         // float key weights (mode 2, non-integral colour weight)
+};
+
+// Generic key: mode 1 = exact u64, mode 2 = double (non-integral colour weight).
+template <int MODE>
+struct KeyT {
+    using type = unsigned long long;
+};
+template <>
+struct KeyT<2> {
+    using type = double;
+};
+
+template <int MODE>
+__device__ __forceinline__ typename KeyT<MODE>::type generic_key(uint32_t p, int x, int y,
+                                                                 uint32_t cl, int cx, int cy,
+                                                                 const AssignParams& P) {
+    int dL = (int)(p & 255) - (int)(cl & 255);
+    int da = (int)((p >> 8) & 255) - (int)((cl >> 8) & 255);
+    int db = (int)((p >> 16) & 255) - (int)((cl >> 16) & 255);
+    unsigned dc2 = dL * dL + da * da + db * db;
+    int dx = x - cx, dy = y - cy;
+    unsigned ds2 = dx * dx + dy * dy;
+    if (MODE == 2) return (typename KeyT<MODE>::type)((double)dc2 * P.S2d + (double)ds2 * P.cw2d);
+    return (typename KeyT<MODE>::type)((unsigned long long)dc2 * P.S2 +
+                                       (unsigned long long)ds2 * P.cw2);
+}
+
+__device__ __forceinline__ void flush_pixel_global(unsigned long long* sums, int label, uint32_t p,
+                                                   int x, int y) {
+    unsigned long long* s = sums + (size_t)label * NFIELD;
+    atomicAdd(&s[0], (unsigned long long)(p & 255));
+    atomicAdd(&s[1], (unsigned long long)((p >> 8) & 255));
+    atomicAdd(&s[2], (unsigned long long)((p >> 16) & 255));
+    atomicAdd(&s[3], (unsigned long long)x);
+    atomicAdd(&s[4], (unsigned long long)y);
+    atomicAdd(&s[5], 1ull);
+}
+
+// MODE 0: u32 key with the dot4 expansion (fast path); 1: u64; 2: double.
+template <int MODE, bool ALIGNED>
+__global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restrict__ lab,
+                                                          int32_t* __restrict__ labels, Ws w,
+                                                          AssignParams P) {
+    __shared__ int s_m;                       // candidates reaching this tile
+    __shared__ int u_idx[MAXC], u_cx[MAXC], u_cy[MAXC], u_lab[MAXC];      // unsorted
+    __shared__ int s_idx[MAXC], s_cx[MAXC], s_cy[MAXC];                    // sorted, tile relative
+    __shared__ uint32_t s_lab[MAXC], s_A[MAXC];
+    __shared__ int s_Bx[MAXC], s_By[MAXC];
+    __shared__ __attribute__((aligned(16))) uint32_t acc[MAXC * 3 * 64];   // [slot][word][lane] lane-private partial sums
+    __shared__ uint32_t red[MAXC * 6];
+
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int H = P.H, W = P.W, S = P.S, n = P.n;
+    const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + TH - 1, H - 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const int4* cand = w.cand + (size_t)b * n;
+    const int* items = w.items + (size_t)b * n;
+    const int* start = w.start + (size_t)b * (w.ncell + 1);
+    unsigned long long* sums = w.sums + (size_t)b * n * NFIELD;
+
+    // centres that can cover a pixel of the tile: cx in [x0-S+1, x1+S], cy likewise
+    const int cxl = max(x0 - S + 1, 0) / S, cxh = min((x1 + S) / S, w.ncx - 1);
+    const int cyl = max(y0 - S + 1, 0) / S, cyh = min((y1 + S) / S, w.ncy - 1);
+
+    if (tid == 0) s_m = 0;
+    __syncthreads();
+    for (int cyc = cyl; cyc <= cyh; ++cyc) {
+        int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
+        for (int i = beg + tid; i < end; i += 256) {
+            int c = items[i];
+            int4 q = cand[c];
+            if (q.x >= x0 - S + 1 && q.x <= x1 + S && q.y >= y0 - S + 1 && q.y <= y1 + S) {
+                int slot = atomicAdd(&s_m, 1);
+                if (slot < MAXC) {
+                    u_idx[slot] = c;
+                    u_cx[slot] = q.x;
+                    u_cy[slot] = q.y;
+                    u_lab[slot] = q.z;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int m = s_m;
+
+    // this lane's 4 pixels
+    const int xr = (lane & 15) * 4, yr = wave * 4 + (lane >> 4);   // tile relative
+    const int x = x0 + xr, y = y0 + yr;
+    const bool rowok = (y < H - 1);
+    uint32_t px[4] = {0, 0, 0, 0};
+    if (rowok && x < W - 1) {
+        const uint8_t* src = lab + (((size_t)b * H + y) * W + x) * 3;
+        if (ALIGNED) {
+            Dword3 v = *reinterpret_cast<const Dword3*>(src);
+            px[0] = v.a & 0xffffffu;
+            px[1] = __builtin_amdgcn_perm(v.b, v.a, 0x0c050403u);
+            px[2] = __builtin_amdgcn_perm(v.c, v.b, 0x0c040302u);
+            px[3] = v.c >> 8;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (x + j < W) {
+                    const uint8_t* s = src + 3 * j;
+                    px[j] = s[0] | (s[1] << 8) | (s[2] << 16);
+                }
+        }
+    }
+    bool valid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) valid[j] = rowok && (x + j < W - 1);
+
+    const size_t lbase = ((size_t)b * H + y) * W + x;
+
+    if (m > MAXC) {
+        // ---- slow path: too many centres around this tile (degenerate inputs).  Every lane
+        // walks the cell lists itself and flushes with global atomics.  Exact, just slower.
+        for (int j = 0; j < 4; ++j) {
+            if (!valid[j]) continue;
+            typename KeyT<MODE == 2 ? 2 : 1>::type best = 0;
+            int bi = -1;
+            for (int cyc = cyl; cyc <= cyh; ++cyc) {
+                int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
+                for (int i = beg; i < end; ++i) {
+                    int c = items[i];
+                    int4 q = cand[c];
+                    if ((unsigned)(x + j - q.x + S) >= (unsigned)(2 * S) ||
+                        (unsigned)(y - q.y + S) >= (unsigned)(2 * S))
+                        continue;
+                    auto k = generic_key<MODE == 2 ? 2 : 1>(px[j], x + j, y, q.z, q.x, q.y, P);
+                    if (bi < 0 || k < best || (k == best && c < bi)) {
+                        best = k;
+                        bi = c;
+                    }
+                }
+            }
+            int lbl = bi;
+            if (bi >= 0)
+                labels[lbase + j] = bi;
+            else
+                lbl = labels[lbase + j];
+            if (lbl >= 0) flush_pixel_global(sums, lbl, px[j], x + j, y);
+        }
+        return;
+    }
+
+    // ---- sort the candidate list by centre index (rank sort, m <= MAXC) and precompute
+    if (tid < m) {
+        int me = u_idx[tid], rank = 0;
+        for (int j = 0; j < m; ++j) rank += (u_idx[j] < me);
+        int cxr = u_cx[tid] - x0, cyr = u_cy[tid] - y0;
+        uint32_t cl = (uint32_t)u_lab[tid];
+        s_idx[rank] = me;
+        s_cx[rank] = cxr;
+        s_cy[rank] = cyr;
+        s_lab[rank] = cl;
+        if (MODE == 0) {
+            uint32_t cc = __builtin_amdgcn_udot4(cl, cl, 0u, false);
+            s_A[rank] = P.S2 * cc + P.cw2 * (uint32_t)(cxr * cxr + cyr * cyr);
+            s_Bx[rank] = 2 * (int)P.cw2 * cxr;
+            s_By[rank] = 2 * (int)P.cw2 * cyr;
+        }
+    }
+    for (int i = tid; i < m * 3 * 64; i += 256) acc[i] = 0;
+    __syncthreads();
+
+    int slot[4] = {-1, -1, -1, -1};
+    const unsigned twoS = 2u * S;
+    if (MODE == 0) {
+        uint32_t best[4], T[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            best[j] = 0xffffffffu;
+            uint32_t pp = __builtin_amdgcn_udot4(px[j], px[j], 0u, false);
+            T[j] = pp * P.S2 + P.cw2 * (uint32_t)((xr + j) * (xr + j) + yr * yr);
+        }
+        const int S2x2 = 2 * (int)P.S2;
+        for (int s = 0; s < m; ++s) {
+            const int cyr = s_cy[s];
+            // wave-level cull: rows of this wave are yr0..yr0+3
+            const int wy0 = wave * 4;
+            if (cyr - S > wy0 + 3 || cyr + S - 1 < wy0) continue;
+            const int cxr = s_cx[s];
+            const uint32_t cl = s_lab[s];
+            const bool iny = (unsigned)(yr - cyr + S) < twoS;
+            const uint32_t R = s_A[s] - (uint32_t)__mul24(s_By[s], yr);
+            const int Bx = s_Bx[s];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t pc = __builtin_amdgcn_udot4(px[j], cl, 0u, false);
+                uint32_t key = T[j] + R - (uint32_t)__mul24(S2x2, (int)pc) -
+                               (uint32_t)__mul24(Bx, xr + j);
+                bool in = iny && ((unsigned)(xr + j - cxr + S) < twoS);
+                if (in && key < best[j]) {
+                    best[j] = key;
+                    slot[j] = s;
+                }
+            }
+        }
+    } else {
+        typename KeyT<MODE>::type best[4];
+        for (int s = 0; s < m; ++s) {
+            const int cyr = s_cy[s], cxr = s_cx[s];
+            const uint32_t cl = s_lab[s];
+            const bool iny = (unsigned)(yr - cyr + S) < twoS;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bool in = iny && ((unsigned)(xr + j - cxr + S) < twoS);
+                auto key = generic_key<MODE>(px[j], xr + j, yr, cl, cxr, cyr, P);
+                if (in && (slot[j] < 0 || key < best[j])) {
+                    best[j] = key;
+                    slot[j] = s;
+                }
+            }
+        }
+    }
+
+    // ---- labels out + accumulate
+    bool all4 = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) all4 = all4 && valid[j] && slot[j] >= 0;
+    if (ALIGNED && all4) {
+        int4 o = make_int4(s_idx[slot[0]], s_idx[slot[1]], s_idx[slot[2]], s_idx[slot[3]]);
+        *reinterpret_cast<int4*>(labels + lbase) = o;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (valid[j] && slot[j] >= 0) labels[lbase + j] = s_idx[slot[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!valid[j]) continue;
+        if (slot[j] >= 0) {
+            uint32_t p = px[j];
+            uint32_t* a = acc + slot[j] * 192 + lane;
+            atomicAdd(a, (p & 0xffu) | ((p & 0xff00u) << 8));
+            atomicAdd(a + 64, ((p >> 16) & 0xffu) | 0x10000u);
+            atomicAdd(a + 128, (uint32_t)(xr + j) | ((uint32_t)yr << 16));
+        } else {
+            int old = labels[lbase + j];      // not covered this round: keeps its label
+            if (old >= 0) flush_pixel_global(sums, old, px[j], x + j, y);
+        }
+    }
+    __syncthreads();
+
+    // ---- reduce the 64 lane-private copies: 4 threads per (slot, word) row, 16 copies each.
+    // Packed halves cannot overflow: a copy sums <= 16 pixels, 16 copies <= 65280 per half.
+    for (int row0 = 0; row0 < m * 3; row0 += 64) {
+        int row = row0 + (tid >> 2), q = tid & 3;
+        uint32_t lo = 0, hi = 0;
+        if (row < m * 3) {
+            const uint4* src = reinterpret_cast<const uint4*>(acc + row * 64 + q * 16);
+            uint32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint4 v = src[k];
+                sum += v.x + v.y + v.z + v.w;
+            }
+            lo = sum & 0xffffu;
+            hi = sum >> 16;
+        }
+        lo += __shfl_xor(lo, 1);
+        hi += __shfl_xor(hi, 1);
+        lo += __shfl_xor(lo, 2);
+        hi += __shfl_xor(hi, 2);
+        if (row < m * 3 && q == 0) {
+            red[row * 2] = lo;
+            red[row * 2 + 1] = hi;
+        }
+    }
+    __syncthreads();
+    // red[slot*6 + {0:L, 1:a, 2:b, 3:count, 4:x', 5:y'}]
+    for (int i = tid; i < m * 6; i += 256) {
+        int s = i / 6, f = i - s * 6;
+        uint32_t cnt = red[s * 6 + 3];
+        if (cnt == 0) continue;
+        unsigned long long v;
+        int field;
+        if (f < 3) {
+            v = red[i];
+            field = f;
+        } else if (f == 3) {
+            v = cnt;
+            field = 5;
+        } else if (f == 4) {
+            v = (unsigned long long)red[i] + (unsigned long long)cnt * x0;
+            field = 3;
+        } else {
+            v = (unsigned long long)red[i] + (unsigned long long)cnt * y0;
+            field = 4;
+        }
+        if (v) atomicAdd(&sums[(size_t)s_idx[s] * NFIELD + field], v);
+    }
+}
+
+// ------------------------------------------------------------------ finalise (slic.py:124-126)
+__global__ void slic_finalise_kernel(int32_t* __restrict__ centres, Ws w, int B, int n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n) return;
+    const unsigned long long* s = w.sums + (size_t)t * NFIELD;
+    unsigned long long cnt = s[5];
+    int32_t* o = centres + (size_t)t * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = cnt ? (int32_t)(s[k] / cnt) : 0;
+}
+
+int key_mode(int S, double cw) {
+    double r = rint(cw);
+    if (r != cw || cw < 1.0 || cw > 4096.0) return 2;
+    double cw2 = cw * cw, S2 = (double)S * S;
+    bool fits32 = S2 * (195075.0 + 2.0 * cw2) < 4294967295.0 && 2.0 * cw2 * (TW + S) < 8388608.0 &&
+                  2.0 * S2 < 8388608.0;
+    return fits32 ? 0 : 1;
+}
+
+int validate(const char* fn, int B, int H, int W, int S, int n) {
+    if (B < 1 || H < 2 || W < 2) return imgan::fail(imgan::E_INVALID, std::string(fn) + ": bad shape");
+    if (S < 1) return imgan::fail(imgan::E_INVALID, std::string(fn) + ": step must be >= 1");
+    if (n < 1) return imgan::fail(imgan::E_INVALID, std::string(fn) + ": no centres");
+    if ((double)H * W * 3 * B > 9.0e18) return imgan::fail(imgan::E_RANGE, std::string(fn) + ": too large");
+    if ((int64_t)B * n > 0x7fffffff) return imgan::fail(imgan::E_RANGE, std::string(fn) + ": too many centres");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int imgan_slic_grid_host(int H, int W, int K, int step_in, int* step, int* nx, int* ny) {
+    IMGAN_REQUIRE(step && nx && ny, "imgan_slic_grid_host: null output");
+    IMGAN_REQUIRE(H > 0 && W > 0, "imgan_slic_grid_host: bad shape");
+    int S = step_in;
+    if (S <= 0) {
+        IMGAN_REQUIRE(K > 0, "imgan_slic_grid_host: num_clusters must be positive");
+        S = (int)sqrt((double)(((int64_t)H * W) / K));        // slic.py:29,33
+    }
+    IMGAN_REQUIRE(S >= 1, "imgan_slic_grid_host: step is 0 (more clusters than pixels)");
+    auto count = [](int lo, int hi, int st) { return hi > lo ? (hi - lo + st - 1) / st : 0; };
+    *step = S;
+    *nx = count(S, W - S / 2, S);                            // slic.py:42
+    *ny = count(S, H - S / 2, S);                            // slic.py:43
+    return 0;
+}
+
+extern "C" size_t imgan_slic_workspace_bytes(int B, int H, int W, int S, int n) {
+    if (B < 1 || H < 1 || W < 1 || S < 1 || n < 1) return 0;
+    return make_layout(B, H, W, S, n).total;
+}
+
+extern "C" int imgan_slic_init(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,
+                               int32_t* centres, int32_t* labels, void* workspace,
+                               imgan_stream_t stream) {
+    IMGAN_REQUIRE(lab && centres && labels && workspace, "imgan_slic_init: null pointer");
+    int n = nx * ny;
+    if (int rc = validate("imgan_slic_init", B, H, W, S, n)) return rc;
+    // the 3x3 search reads (x+2, y) and (x, y+2) around the last seed (slic.py:65-66)
+    IMGAN_REQUIRE(S + (nx - 1) * S + 2 <= W - 1 && S + (ny - 1) * S + 2 <= H - 1,
+                  "imgan_slic_init: seed grid too close to the image border (index out of bounds)");
+    hipStream_t st = (hipStream_t)stream;
+    IMGAN_HIP(hipMemsetAsync(labels, 0xff, (size_t)B * H * W * 4, st));
+    int total = B * n;
+    hipLaunchKernelGGL(slic_init_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, lab,
+                       centres, B, H, W, S, nx, ny);
+    return imgan::check_launch("slic_init_kernel");
+}
+
+extern "C" int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres, int B, int H,
+                                      int W, int S, int n, void* workspace,
+                                      imgan_stream_t stream) {
+    IMGAN_REQUIRE(lab && centres && workspace, "imgan_slic_bin_centres: null pointer");
+    if (int rc = validate("imgan_slic_bin_centres", B, H, W, S, n)) return rc;
+    Layout L = make_layout(B, H, W, S, n);
+    Ws w = bind(workspace, L);
+    hipStream_t st = (hipStream_t)stream;
+    // count and fill are adjacent in the layout: one memset clears both
+    IMGAN_HIP(hipMemsetAsync(w.count, 0, L.off_start - L.off_count, st));
+    int total = B * n;
+    hipLaunchKernelGGL(slic_prepare_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, lab,
+                       centres, w, B, H, W, S, n);
+    hipLaunchKernelGGL(slic_scan_kernel, dim3(B), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL(slic_fill_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, w, B, n);
+    return imgan::check_launch("slic_bin_centres");
+}
+
+extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H,
+                                            int W, int S, int n, double colour_weight,
+                                            void* workspace, imgan_stream_t stream) {
+    IMGAN_REQUIRE(lab && labels && workspace, "imgan_slic_assign_accumulate: null pointer");
+    if (int rc = validate("imgan_slic_assign_accumulate", B, H, W, S, n)) return rc;
+    IMGAN_REQUIRE(colour_weight > 0.0 && isfinite(colour_weight),
+                  "imgan_slic_assign_accumulate: colour_weight must be positive");
+    IMGAN_REQUIRE(B <= 65535, "imgan_slic_assign_accumulate: batch > 65535, split the call");
+    Layout L = make_layout(B, H, W, S, n);
+    Ws w = bind(workspace, L);
+    AssignParams P;
+    P.B = B; P.H = H; P.W = W; P.S = S; P.n = n;
+    P.S2d = (double)S * S;
+    P.cw2d = colour_weight * colour_weight;
+    int mode = key_mode(S, colour_weight);
+    P.S2 = (unsigned)(S * S);
+    P.cw2 = mode == 2 ? 0u : (unsigned)(colour_weight * colour_weight);
+    bool aligned = (W % 4 == 0) && (((uintptr_t)lab & 3) == 0) && (((uintptr_t)labels & 15) == 0);
+    dim3 grid((unsigned)imgan::cdiv(W - 1, TW), (unsigned)imgan::cdiv(H - 1, TH), (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(M, A) hipLaunchKernelGGL((slic_assign_kernel<M, A>), grid, dim3(256), 0, st, lab, labels, w, P)
+    if (mode == 0) { if (aligned) LAUNCH(0, true); else LAUNCH(0, false); }
+    else if (mode == 1) { if (aligned) LAUNCH(1, true); else LAUNCH(1, false); }
+    else { if (aligned) LAUNCH(2, true); else LAUNCH(2, false); }
+#undef LAUNCH
+    return imgan::check_launch("slic_assign_kernel");
+}
+
+extern "C" int imgan_slic_finalise_centres(int32_t* centres, int B, int H, int W, int S, int n,
+                                           void* workspace, imgan_stream_t stream) {
+    IMGAN_REQUIRE(centres && workspace, "imgan_slic_finalise_centres: null pointer");
+    if (int rc = validate("imgan_slic_finalise_centres", B, H, W, S, n)) return rc;
+    Ws w = bind(workspace, make_layout(B, H, W, S, n));
+    hipLaunchKernelGGL(slic_finalise_kernel, dim3(imgan::cdiv(B * n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, centres, w, B, n);
+    return imgan::check_launch("slic_finalise_kernel");
+}
+
+extern "C" int imgan_slic_run(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,
+                              double colour_weight, int num_iter, int32_t* centres,
+                              int32_t* labels, void* workspace, imgan_stream_t stream) {
+    int n = nx * ny;
+    if (int rc = imgan_slic_init(lab, B, H, W, S, nx, ny, centres, labels, workspace, stream))
+        return rc;
+    for (int it = 1; it < num_iter; ++it) {                  // slic.py:84 -> num_iter - 1 rounds
+        if (int rc = imgan_slic_bin_centres(lab, centres, B, H, W, S, n, workspace, stream))
+            return rc;
+        if (int rc = imgan_slic_assign_accumulate(lab, labels, B, H, W, S, n, colour_weight,
+                                                  workspace, stream))
+            return rc;
+        if (int rc = imgan_slic_finalise_centres(centres, B, H, W, S, n, workspace, stream))
+            return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,163 @@
+/* libimgan_hip.so -- C ABI of the MI355X (gfx950) SLIC / RAG / MPEG-7 hot path.
+ *
+ * The reference (filip141/Image-analysis) has no FFI: its boundary is the set of
+ * Python classes in scripts/{slic,rag_segmentation,mpeg7Descriptors}.py.  Each
+ * entry point below cites the reference code it replaces; the Python classes of
+ * the same names in image-analysis_amd/ bind these symbols through ctypes
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error (IMGAN_E_*); the message
+ *    is available from imgan_last_error() (thread local).
+ *  - no ownership transfer: the caller allocates every buffer.  Pointers are
+ *    DEVICE pointers on the current HIP device unless the name says `host`.
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *    nothing synchronises unless stated.  Calls are thread-safe per stream as
+ *    long as they do not share a workspace.
+ *  - images are u8, interleaved, batch first: [B][H][W][3] (cv2 BGR order);
+ *    label maps are int32 [B][H][W] with -1 = unassigned (the reference keeps
+ *    float64 label maps; the Python layer converts at the boundary).
+ */
+#ifndef IMGAN_H
+#define IMGAN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMGAN_OK 0
+#define IMGAN_E_INVALID (-1)
+#define IMGAN_E_HIP (-2)
+#define IMGAN_E_RANGE (-3)
+#define IMGAN_E_NOMEM (-4)
+
+typedef void* imgan_stream_t;
+
+const char* imgan_last_error(void);
+int imgan_version(void);
+
+/* ---- colour conversion ---------------------------------------------------
+ * Replaces cv2.cvtColor(img, COLOR_BGR2Lab) at slic.py:13,
+ * rag_segmentation.py:12, mpeg7Descriptors.py:22 and COLOR_BGR2GRAY at
+ * mpeg7Descriptors.py:23 (8-bit fixed-point OpenCV algorithm). */
+int imgan_lab_tables_host(uint16_t* gamma256, uint16_t* cbrt3072, int32_t* coeffs9);
+int imgan_bgr2lab_u8(const uint8_t* bgr, uint8_t* lab, int64_t npix, imgan_stream_t stream);
+int imgan_bgr2gray_u8(const uint8_t* bgr, uint8_t* gray, int64_t npix, imgan_stream_t stream);
+
+/* Replaces cv2.medianBlur(image, 7) at rag_segmentation.py:11 (3 channels,
+ * replicated border). */
+int imgan_median7_u8c3(const uint8_t* src, uint8_t* dst, int B, int H, int W,
+                       imgan_stream_t stream);
+
+/* ---- SLIC ------------------------------------------------------------------
+ * imgan_slic_grid: slic.py:29,33 (step) and :42-43 (seed grid); host only.
+ * step_in <= 0 selects the default int(sqrt(H*W / K)). */
+int imgan_slic_grid_host(int H, int W, int K, int step_in, int* step, int* nx, int* ny);
+
+/* Bytes of device workspace the SLIC calls need for B images of H x W with n centres. */
+size_t imgan_slic_workspace_bytes(int B, int H, int W, int S, int n);
+
+/* slic.py:35-54 + :57-76 (init_clusters / find_local_minimum) and :81 (labels = -1).
+ * centres: int32 [B][n][5] = L,a,b,x,y, n = nx*ny, index = ix*ny + iy. */
+int imgan_slic_init(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,
+                    int32_t* centres, int32_t* labels, void* workspace, imgan_stream_t stream);
+
+/* Re-bin the centres into S x S cells (candidate lookup for the next assignment). */
+int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres, int B, int H, int W, int S,
+                           int n, void* workspace, imgan_stream_t stream);
+
+/* slic.py:85-116 (assignment over the 2S x 2S windows) fused with the sums of
+ * :118-125.  colour_weight: slic.py:109.  Labels are updated in place. */
+int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H, int W, int S,
+                                 int n, double colour_weight, void* workspace,
+                                 imgan_stream_t stream);
+
+/* slic.py:124-126: centre = floor(sum / count), empty cluster -> 0. */
+int imgan_slic_finalise_centres(int32_t* centres, int B, int H, int W, int S, int n,
+                                void* workspace, imgan_stream_t stream);
+
+/* SLICSuperPixel.run(), slic.py:78-127: init + (num_iter-1) x (bin, assign, finalise). */
+int imgan_slic_run(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,
+                   double colour_weight, int num_iter, int32_t* centres, int32_t* labels,
+                   void* workspace, imgan_stream_t stream);
+
+/* ---- RAG -------------------------------------------------------------------
+ * rag_segmentation.py:38-48 (per-label colour sums) and :50-74 (8-connected
+ * adjacency) in one pass.  sums: uint64 [B][K][4] = sum c0,c1,c2,count.
+ * edges: per image an open-addressed hash set of uint64 keys
+ * ((min+1)<<32 | (max+1)), 0 = empty, capacity `edge_cap` (power of two);
+ * must be zero-filled by the caller.  Labels >= K are ignored for sums. */
+int imgan_rag_accumulate(const uint8_t* img, const int32_t* labels, int B, int H, int W, int K,
+                         uint64_t* sums, uint64_t* edges, int64_t edge_cap,
+                         imgan_stream_t stream);
+
+/* rag_segmentation.py:77-184 on the host: edge weights from the floor means,
+ * stable sort, Kruskal, leave-one-out mean + c*sigma cut, Kruskal again,
+ * 1-based ids in surviving-set order.  All pointers are HOST pointers.
+ * means: int32 [K][3]; edges_uv: int32 [E][2] (u < v, any order);
+ * lut_out: int32 [K] new id per vertex; mst_out: int32 [<=K][2] kept edges,
+ * mst_w2_out their squared weights; n_mst_out / n_sets_out counts. */
+int imgan_rag_merge_host(const int32_t* means, int K, const int32_t* edges_uv, int64_t E,
+                         double c_factor, int32_t* lut_out, int32_t* mst_out,
+                         int64_t* mst_w2_out, int32_t* n_mst_out, int32_t* n_sets_out);
+
+/* rag_segmentation.py:175-182: out[p] = lut[labels[p]] (labels[p] < 0 or >= K -> 0).
+ * lut: int32 [B][K] device. */
+int imgan_relabel_lut(const int32_t* labels, const int32_t* lut, int32_t* out, int B,
+                      int64_t npix_per_image, int K, imgan_stream_t stream);
+
+/* rag_segmentation.py:34,46: paint the per-label mean colour back into the image. */
+int imgan_paint_means(uint8_t* img, const int32_t* labels, const uint8_t* means_u8, int B,
+                      int64_t npix_per_image, int K, imgan_stream_t stream);
+
+/* ---- connected components ---------------------------------------------------
+ * Label-propagation union-find over equal-valued 8-connected pixels
+ * (mpeg7Descriptors.py:40-74,118-128 flood fill).  values: int32 [B][H][W],
+ * values < 0 are background.  roots: int32 [B][H][W] = smallest raster index of
+ * the component (image relative), -1 for background. */
+int imgan_cc_label(const int32_t* values, int32_t* roots, int B, int H, int W,
+                   imgan_stream_t stream);
+
+/* ---- dominant colour (mpeg7Descriptors.py:76-130) ----------------------------
+ * Segments are given by an int32 label map (ids 0..nseg-1, <0 ignored).
+ * centres: float32 [B][nseg][k][3], in/out (initial centres injected by caller).
+ * assign: uint8 [B][H][W] cluster index per pixel (0xFF outside any segment).
+ * state: per-segment loop state, imgan_dcd_state_bytes() bytes, zero-filled
+ * before the first round.  One call = one Lloyd round (:86-107) for every
+ * segment that has not met the stop rule yet.  active_out (device int32[1],
+ * may be NULL) receives the number of segments still running. */
+size_t imgan_dcd_state_bytes(int B, int nseg, int k);
+int imgan_dcd_kmeans_round(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
+                           int nseg, int k, float* centres, uint8_t* assign, void* state,
+                           int32_t* active_out, imgan_stream_t stream);
+
+/* mpeg7Descriptors.py:110-129: per (segment, colour) integer statistics.
+ * stats: uint64 [B][nseg][k][8] = count, sum c0..c2, sum of squares c0..c2,
+ * size of the largest 8-connected component.  scratch: int32 [B][H][W] x 2. */
+int imgan_dcd_stats(const uint8_t* lab, const int32_t* labels, const uint8_t* assign, int B, int H,
+                    int W, int nseg, int k, uint64_t* stats, int32_t* scratch,
+                    imgan_stream_t stream);
+
+/* ---- MPEG-7 colour layout / edge histogram / colour structure ----------------
+ * Not present in the reference; defined from ISO/IEC 15938-3,
+ * see oracle/mpeg7_std.py.  Whole-image descriptors, one per batch entry.
+ * cld_out: int32 [B][3][64] quantised Y/Cb/Cr coefficients in zig-zag order.
+ * ehd_out: int32 [B][96] = 80 bin counts + 16 blocks-per-subimage.
+ * csd_out: int32 [B][nbins+1] = nbins window counts + number of windows. */
+int imgan_cld(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out, void* scratch,
+              imgan_stream_t stream);
+size_t imgan_cld_scratch_bytes(int B);
+int imgan_ehd(const uint8_t* bgr, int B, int H, int W, int32_t* ehd_out, void* scratch,
+              imgan_stream_t stream);
+size_t imgan_ehd_scratch_bytes(int B, int H, int W);
+int imgan_csd(const uint8_t* bgr, int B, int H, int W, int nbins, int32_t* csd_out,
+              imgan_stream_t stream);
+int imgan_hmmd_quantise(const uint8_t* bgr, uint8_t* out, int64_t npix, int nbins,
+                        imgan_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMGAN_H */
