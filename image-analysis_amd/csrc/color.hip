@@ -28,9 +28,13 @@ constexpr int LAB_SHIFT = 12, LAB_SHIFT2 = 15;
 constexpr int LSCALE = (116 * 255 + 50) / 100;
 constexpr int LSHIFT = -((16 * 255 * (1 << LAB_SHIFT2) + 50) / 100);
 
-__device__ __forceinline__ uint32_t lab_px(const uint16_t* __restrict__ sg,
-                                           const uint16_t* __restrict__ sc, uint32_t b8,
-                                           uint32_t g8, uint32_t r8, const int* __restrict__ C) {
+struct Lab3 {
+    uint32_t L, a, b;
+};
+
+__device__ __forceinline__ Lab3 lab_px(const uint16_t* __restrict__ sg,
+                                       const uint16_t* __restrict__ sc, uint32_t b8,
+                                       uint32_t g8, uint32_t r8, const int* __restrict__ C) {
     int R = sg[r8], G = sg[g8], B = sg[b8];
     int fX = sc[(R * C[0] + G * C[1] + B * C[2] + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
     int fY = sc[(R * C[3] + G * C[4] + B * C[5] + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
@@ -38,10 +42,18 @@ __device__ __forceinline__ uint32_t lab_px(const uint16_t* __restrict__ sg,
     int L = (LSCALE * fY + LSHIFT + (1 << (LAB_SHIFT2 - 1))) >> LAB_SHIFT2;
     int a = (500 * (fX - fY) + 128 * (1 << LAB_SHIFT2) + (1 << (LAB_SHIFT2 - 1))) >> LAB_SHIFT2;
     int b = (200 * (fY - fZ) + 128 * (1 << LAB_SHIFT2) + (1 << (LAB_SHIFT2 - 1))) >> LAB_SHIFT2;
+    // Keep the shift and the clamp apart: hipcc (ROCm 7.2) fuses "sat_u8(x >> 15)" pairs into
+    // v_ashr_pk_u8_i32 and then assumes bits 31:16 of its result are zero; on gfx950 they are
+    // not, which corrupted the neighbouring byte of the packed output.
+    asm volatile("" : "+v"(L), "+v"(a), "+v"(b));
     L = min(max(L, 0), 255);
     a = min(max(a, 0), 255);
     b = min(max(b, 0), 255);
-    return (uint32_t)L | ((uint32_t)a << 8) | ((uint32_t)b << 16);
+    Lab3 o;
+    o.L = (uint32_t)L & 255u;
+    o.a = (uint32_t)a & 255u;
+    o.b = (uint32_t)b & 255u;
+    return o;
 }
 
 struct Coeffs {
@@ -63,23 +75,23 @@ __global__ __launch_bounds__(256) void bgr2lab_kernel(const uint8_t* __restrict_
          q += (int64_t)gridDim.x * 256) {
         Dword3 v = s3[q];
         // bytes: b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
-        uint32_t p0 = lab_px(sg, sc, v.a & 255, (v.a >> 8) & 255, (v.a >> 16) & 255, cf.c);
-        uint32_t p1 = lab_px(sg, sc, v.a >> 24, v.b & 255, (v.b >> 8) & 255, cf.c);
-        uint32_t p2 = lab_px(sg, sc, (v.b >> 16) & 255, v.b >> 24, v.c & 255, cf.c);
-        uint32_t p3 = lab_px(sg, sc, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24, cf.c);
+        Lab3 p0 = lab_px(sg, sc, v.a & 255, (v.a >> 8) & 255, (v.a >> 16) & 255, cf.c);
+        Lab3 p1 = lab_px(sg, sc, v.a >> 24, v.b & 255, (v.b >> 8) & 255, cf.c);
+        Lab3 p2 = lab_px(sg, sc, (v.b >> 16) & 255, v.b >> 24, v.c & 255, cf.c);
+        Lab3 p3 = lab_px(sg, sc, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24, cf.c);
         Dword3 o;
-        o.a = p0 | (p1 << 24);
-        o.b = (p1 >> 8) | (p2 << 16);
-        o.c = (p2 >> 16) | (p3 << 8);
+        o.a = p0.L | (p0.a << 8) | (p0.b << 16) | (p1.L << 24);
+        o.b = p1.a | (p1.b << 8) | (p2.L << 16) | (p2.a << 24);
+        o.c = p2.b | (p3.L << 8) | (p3.a << 16) | (p3.b << 24);
         d3[q] = o;
     }
     // tail (npix % 4 pixels), one lane each
     if (blockIdx.x == 0 && threadIdx.x < (npix & 3)) {
         int64_t p = (nquad << 2) + threadIdx.x;
-        uint32_t o = lab_px(sg, sc, src[3 * p], src[3 * p + 1], src[3 * p + 2], cf.c);
-        dst[3 * p] = o & 255;
-        dst[3 * p + 1] = (o >> 8) & 255;
-        dst[3 * p + 2] = (o >> 16) & 255;
+        Lab3 o = lab_px(sg, sc, src[3 * p], src[3 * p + 1], src[3 * p + 2], cf.c);
+        dst[3 * p] = (uint8_t)o.L;
+        dst[3 * p + 1] = (uint8_t)o.a;
+        dst[3 * p + 2] = (uint8_t)o.b;
     }
 }
 

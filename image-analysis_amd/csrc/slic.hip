@@ -180,10 +180,26 @@ struct __attribute__((packed, aligned(4))) Dword3 {
 struct AssignParams {
     int B, H, W, S, n;
     unsigned S2, cw2;         // integer key weights (modes 0, 1)
-    double S2d, cw2d;         // float key weights (mode 2, non-integral colour weight)
+    double Sd, cw;            // literal float64 evaluation (mode 2 and exact-key ties)
 };
 
-// Generic key: mode 1 = exact u64, mode 2 = double (non-integral colour weight).
+// slic.py:101-109 evaluated literally in float64 (numpy order of operations, no contraction):
+//   dc = sqrt(sum(square(dLab))); ds = sqrt(dx^2 + dy^2); D = sqrt((dc/cw)^2 + (ds/S)^2)
+__device__ __attribute__((noinline)) double literal_dist(uint32_t p, int x, int y, uint32_t cl,
+                                                         int cx, int cy, double Sd, double cw) {
+    int dL = (int)(p & 255) - (int)(cl & 255);
+    int da = (int)((p >> 8) & 255) - (int)((cl >> 8) & 255);
+    int db = (int)((p >> 16) & 255) - (int)((cl >> 16) & 255);
+    int dx = x - cx, dy = y - cy;
+    double dc = sqrt((double)(dL * dL + da * da + db * db));
+    double ds = sqrt((double)(dx * dx + dy * dy));
+    double u = dc / cw, v = ds / Sd;
+    return sqrt(u * u + v * v);
+}
+
+// Generic key: mode 1 = exact u64 (same order as the float64 expression whenever the keys
+// differ: distinct integer keys below 2^64 differ by far more than the float64 rounding of
+// the expression); mode 2 = the literal float64 distance (non-integral colour weight).
 template <int MODE>
 struct KeyT {
     using type = unsigned long long;
@@ -203,7 +219,7 @@ __device__ __forceinline__ typename KeyT<MODE>::type generic_key(uint32_t p, int
     unsigned dc2 = dL * dL + da * da + db * db;
     int dx = x - cx, dy = y - cy;
     unsigned ds2 = dx * dx + dy * dy;
-    if (MODE == 2) return (typename KeyT<MODE>::type)((double)dc2 * P.S2d + (double)ds2 * P.cw2d);
+    if (MODE == 2) return (typename KeyT<MODE>::type)literal_dist(p, x, y, cl, cx, cy, P.Sd, P.cw);
     return (typename KeyT<MODE>::type)((unsigned long long)dc2 * P.S2 +
                                        (unsigned long long)ds2 * P.cw2);
 }
@@ -312,7 +328,16 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
                         (unsigned)(y - q.y + S) >= (unsigned)(2 * S))
                         continue;
                     auto k = generic_key<MODE == 2 ? 2 : 1>(px[j], x + j, y, q.z, q.x, q.y, P);
-                    if (bi < 0 || k < best || (k == best && c < bi)) {
+                    bool take = bi < 0 || k < best;
+                    if (!take && k == best) {
+                        // equal exact keys: the reference compares the rounded float64 values,
+                        // and on equality the lower centre index (earlier in its sweep) stays
+                        double dn = literal_dist(px[j], x + j, y, q.z, q.x, q.y, P.Sd, P.cw);
+                        int4 qb = cand[bi];
+                        double db = literal_dist(px[j], x + j, y, qb.z, qb.x, qb.y, P.Sd, P.cw);
+                        take = dn < db || (dn == db && c < bi);
+                    }
+                    if (take) {
                         best = k;
                         bi = c;
                     }
@@ -375,9 +400,19 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
                 uint32_t key = T[j] + R - (uint32_t)__mul24(S2x2, (int)pc) -
                                (uint32_t)__mul24(Bx, xr + j);
                 bool in = iny && ((unsigned)(xr + j - cxr + S) < twoS);
-                if (in && key < best[j]) {
-                    best[j] = key;
-                    slot[j] = s;
+                if (in && key <= best[j]) {
+                    bool take = key < best[j];
+                    if (!take && slot[j] >= 0) {
+                        // equal exact keys (rare): the reference compares the float64 values
+                        int sb = slot[j];
+                        take = literal_dist(px[j], xr + j, yr, cl, cxr, cyr, P.Sd, P.cw) <
+                               literal_dist(px[j], xr + j, yr, s_lab[sb], s_cx[sb], s_cy[sb], P.Sd,
+                                            P.cw);
+                    }
+                    if (take) {
+                        best[j] = key;
+                        slot[j] = s;
+                    }
                 }
             }
         }
@@ -390,8 +425,15 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 bool in = iny && ((unsigned)(xr + j - cxr + S) < twoS);
+                if (!in) continue;
                 auto key = generic_key<MODE>(px[j], xr + j, yr, cl, cxr, cyr, P);
-                if (in && (slot[j] < 0 || key < best[j])) {
+                bool take = slot[j] < 0 || key < best[j];
+                if (MODE == 1 && !take && key == best[j]) {
+                    int sb = slot[j];
+                    take = literal_dist(px[j], xr + j, yr, cl, cxr, cyr, P.Sd, P.cw) <
+                           literal_dist(px[j], xr + j, yr, s_lab[sb], s_cx[sb], s_cy[sb], P.Sd, P.cw);
+                }
+                if (take) {
                     best[j] = key;
                     slot[j] = s;
                 }
@@ -576,8 +618,8 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
     Ws w = bind(workspace, L);
     AssignParams P;
     P.B = B; P.H = H; P.W = W; P.S = S; P.n = n;
-    P.S2d = (double)S * S;
-    P.cw2d = colour_weight * colour_weight;
+    P.Sd = (double)S;
+    P.cw = colour_weight;
     int mode = key_mode(S, colour_weight);
     P.S2 = (unsigned)(S * S);
     P.cw2 = mode == 2 ? 0u : (unsigned)(colour_weight * colour_weight);

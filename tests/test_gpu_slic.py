@@ -62,20 +62,19 @@ def test_slic_matches_oracle(H, W, K, cw, iters):
     got = sp.get_clusters()
     assert got.dtype == np.float64 and got.shape == (H, W)
 
-    exact = SLICOracle(img, K, colour_weight=cw, num_iter=iters, mode="intkey")
-    exact.run()
-    assert sp.step == exact.step and len(sp.centers) == len(exact.centers)
-    # the kernel evaluates the exact integer ordering: bit exact against the integer oracle
-    assert np.array_equal(got, exact.get_clusters())
-    assert sp.centers == [list(map(int, c)) for c in exact.centers]
-
-    # literal float64 oracle (slic.py:101-109): >= 99.9 % agreement (float ties, north_star)
+    # literal float64 oracle (slic.py:101-109).  north_star asks for >= 99.9 % agreement; the
+    # kernel orders candidates by the exact integer key and falls back to the literal float64
+    # expression only when two keys are equal, which reproduces the reference's float ties,
+    # so the labels and the final centres are expected to be identical.
     lit = SLICOracle(img, K, colour_weight=cw, num_iter=iters, mode="float64")
     lit.run()
+    assert sp.step == lit.step and len(sp.centers) == len(lit.centers)
     agree = float((got == lit.get_clusters()).mean())
     assert agree >= 0.999, agree
-    # reference quirks: last row / column never labelled
-    assert (got[-1, :] == -1).all() and (got[:, -1] == -1).all() and (got[:-1, :-1] >= 0).all()
+    assert np.array_equal(got, lit.get_clusters()), agree
+    assert sp.centers == [list(map(int, c)) for c in lit.centers]
+    # reference quirk: last row / column never labelled
+    assert (got[-1, :] == -1).all() and (got[:, -1] == -1).all()
 
 
 def test_slic_noninteger_colour_weight():
@@ -87,7 +86,7 @@ def test_slic_noninteger_colour_weight():
     sp.run()
     lit = SLICOracle(img, 40, colour_weight=12.5, num_iter=5, mode="float64")
     lit.run()
-    assert float((sp.get_clusters() == lit.get_clusters()).mean()) >= 0.999
+    assert np.array_equal(sp.get_clusters(), lit.get_clusters())
 
 
 def test_slic_init_matches_oracle_and_kat():
