@@ -118,15 +118,20 @@ class SlicPlan(object):
                                   _ptr(self.centres), _ptr(self.labels), _ptr(self.workspace),
                                   _stream()))
 
-    def round(self, lab, colour_weight):
-        """One iteration of slic.py:84-126."""
+    def round(self, lab, colour_weight, events=None):
+        """One iteration of slic.py:84-126.  `events`: optional (start, end) torch events
+        recorded around the assignment kernel on the current stream (bench.py roofline)."""
         lab = self._check(lab)
         a = (self.B, self.H, self.W, self.S, self.n)
         check(lib.imgan_slic_bin_centres(_ptr(lab), _ptr(self.centres), *a, _ptr(self.workspace),
                                          _stream()))
+        if events:
+            events[0].record()
         check(lib.imgan_slic_assign_accumulate(_ptr(lab), _ptr(self.labels), *a,
                                                float(colour_weight), _ptr(self.workspace),
                                                _stream()))
+        if events:
+            events[1].record()
         check(lib.imgan_slic_finalise_centres(_ptr(self.centres), *a, _ptr(self.workspace),
                                               _stream()))
 
