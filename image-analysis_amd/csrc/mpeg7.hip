@@ -1,0 +1,434 @@
+// MPEG-7 colour layout (CLD), edge histogram (EHD) and colour structure (CSD) descriptors.
+// NOT in the reference; defined from ISO/IEC 15938-3 / the XM
+// software in oracle/mpeg7_std.py, which these kernels follow bit for bit.  Every decision is
+// taken in exact integer arithmetic; the only floating point is the CLD colour transform and
+// 8x8 DCT, in double with a fixed operation order (build uses -ffp-contract=off).
+//
+// All three are one streaming pass over the BGR image (3 B/px; CSD only touches the
+// sub-sampled grid).  Sums are aggregated per wave (a run of 64 pixels of one row falls into
+// very few blocks / quadrants) before any atomic is issued; CSD builds its 256-bin histogram
+// in LDS (privatised per workgroup) and flushes once.
+#include "common.h"
+#include "../../include/imgan.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t gray_px(uint32_t b, uint32_t g, uint32_t r) {
+    return (4899u * r + 9617u * g + 1868u * b + 8192u) >> 14;
+}
+
+// ------------------------------------------------------------------------------ CLD
+// sums: u64 [B][64][4] = B, G, R sums and pixel count of the 8x8 grid blocks
+__global__ __launch_bounds__(256) void cld_sums_kernel(const uint8_t* __restrict__ img, int H,
+                                                       int W, unsigned long long* __restrict__ sums) {
+    const int b = blockIdx.y;
+    const long long npix = (long long)H * W;
+    const uint8_t* im = img + (size_t)b * npix * 3;
+    unsigned long long* S = sums + (size_t)b * 64 * 4;
+    const long long chunk = (long long)blockIdx.x * (256 * 8);
+    for (int it = 0; it < 8; ++it) {
+        long long p = chunk + (long long)it * 256 + threadIdx.x;
+        int pending = -1;
+        uint32_t c0 = 0, c1 = 0, c2 = 0;
+        if (p < npix) {
+            int y = (int)(p / W), x = (int)(p - (long long)y * W);
+            pending = ((y * 8) / H) * 8 + (x * 8) / W;
+            const uint8_t* q = im + p * 3;
+            c0 = q[0];
+            c1 = q[1];
+            c2 = q[2];
+        }
+        while (true) {
+            unsigned long long act = __ballot(pending >= 0);
+            if (act == 0ull) break;
+            int leader = __ffsll((long long)act) - 1;
+            int cur = __shfl(pending, leader);
+            bool mine = (pending == cur);
+            uint32_t w0 = wave_sum(mine ? (c0 | (c1 << 16)) : 0u);
+            uint32_t w1 = wave_sum(mine ? (c2 | (1u << 16)) : 0u);
+            if ((int)(threadIdx.x & 63) == leader) {
+                unsigned long long* s = S + (size_t)cur * 4;
+                atomicAdd(&s[0], (unsigned long long)(w0 & 0xffffu));
+                atomicAdd(&s[1], (unsigned long long)(w0 >> 16));
+                atomicAdd(&s[2], (unsigned long long)(w1 & 0xffffu));
+                atomicAdd(&s[3], (unsigned long long)(w1 >> 16));
+            }
+            if (mine) pending = -1;
+        }
+    }
+}
+
+struct DctTable {
+    double c[64];
+};
+
+__device__ const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                                        12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                        35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                                        58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+__device__ int quant_ydc(int i) {
+    if (i > 192) return 112 + (i - 192) / 4;
+    if (i > 160) return 96 + (i - 160) / 2;
+    if (i > 96) return 32 + (i - 96);
+    if (i > 64) return 16 + (i - 64) / 2;
+    return i >= 0 ? i / 4 : -((-i + 3) / 4);          // floor division like the oracle's '//'
+}
+__device__ int quant_cdc(int i) {
+    if (i > 191) return 63;
+    if (i > 160) return 56 + (i - 160) / 4;
+    if (i > 144) return 48 + (i - 144) / 2;
+    if (i > 112) return 16 + (i - 112);
+    if (i > 96) return 8 + (i - 96) / 2;
+    if (i > 64) return (i - 64) / 4;
+    return 0;
+}
+__device__ int quant_ac(int i) {
+    i = min(i, 239);
+    i = max(i, -256);
+    int a = abs(i), j;
+    if (a > 127) j = 64 + a / 4;
+    else if (a > 63) j = 32 + a / 2;
+    else j = a;
+    j = i < 0 ? -j : j;
+    return j + 128;
+}
+
+// one thread per (image, channel): averages -> YCbCr -> 8x8 DCT -> zig-zag -> quantise
+__global__ void cld_finalise_kernel(const unsigned long long* __restrict__ sums, int B,
+                                    int32_t* __restrict__ out, DctTable T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * 3) return;
+    int b = t / 3, ch = t - b * 3;
+    const unsigned long long* S = sums + (size_t)b * 64 * 4;
+    double blk[64], tmp[64];
+    for (int k = 0; k < 64; ++k) {
+        unsigned long long n = S[4 * k + 3];
+        double Bc = 0.0, Gc = 0.0, Rc = 0.0;
+        if (n) {
+            Bc = (double)(S[4 * k] / n);
+            Gc = (double)(S[4 * k + 1] / n);
+            Rc = (double)(S[4 * k + 2] / n);
+        }
+        double yy = (0.299 * Rc + 0.587 * Gc + 0.114 * Bc) / 256.0;
+        double v;
+        if (ch == 0) v = (double)(int)(219.0 * yy + 16.5);
+        else if (ch == 1) v = (double)(int)(224.0 * 0.564 * (Bc / 256.0 * 1.0 - yy) + 128.5);
+        else v = (double)(int)(224.0 * 0.713 * (Rc / 256.0 * 1.0 - yy) + 128.5);
+        blk[k] = v;
+    }
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 8; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 8; ++k) s += T.c[j * 8 + k] * blk[8 * i + k];
+            tmp[8 * i + j] = s;
+        }
+    int coef[64];
+    for (int j = 0; j < 8; ++j)
+        for (int i = 0; i < 8; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < 8; ++k) s += T.c[i * 8 + k] * tmp[8 * k + j];
+            coef[8 * i + j] = (int)floor(s + 0.499999);
+        }
+    int32_t* o = out + ((size_t)b * 3 + ch) * 64;
+    o[0] = ch == 0 ? (quant_ydc(coef[0] / 8) >> 1) : quant_cdc(coef[0] / 8);
+    for (int i = 1; i < 64; ++i) {
+        int v = coef[kZigzag[i]];
+        o[i] = ch == 0 ? (quant_ac(v / 2) >> 3) : (quant_ac(v) >> 3);
+    }
+}
+
+// ------------------------------------------------------------------------------ EHD
+// qsum: u32 [B][nby*nbx][4] quadrant gray sums (zero-filled by the host wrapper)
+__global__ __launch_bounds__(256) void ehd_sums_kernel(const uint8_t* __restrict__ img, int H,
+                                                       int W, int bs, int nbx, int nby,
+                                                       uint32_t* __restrict__ qsum) {
+    const int b = blockIdx.y;
+    const long long npix = (long long)H * W;
+    const uint8_t* im = img + (size_t)b * npix * 3;
+    uint32_t* Q = qsum + (size_t)b * nbx * nby * 4;
+    const int hb = bs >> 1;
+    const long long chunk = (long long)blockIdx.x * (256 * 8);
+    for (int it = 0; it < 8; ++it) {
+        long long p = chunk + (long long)it * 256 + threadIdx.x;
+        int pending = -1;
+        uint32_t g = 0;
+        if (p < npix) {
+            int y = (int)(p / W), x = (int)(p - (long long)y * W);
+            int bx = x / bs, by = y / bs;
+            if (bx < nbx && by < nby) {
+                int qx = (x - bx * bs) >= hb, qy = (y - by * bs) >= hb;
+                pending = (by * nbx + bx) * 4 + qy * 2 + qx;
+                const uint8_t* q = im + p * 3;
+                g = gray_px(q[0], q[1], q[2]);
+            }
+        }
+        while (true) {
+            unsigned long long act = __ballot(pending >= 0);
+            if (act == 0ull) break;
+            int leader = __ffsll((long long)act) - 1;
+            int cur = __shfl(pending, leader);
+            bool mine = (pending == cur);
+            uint32_t s = wave_sum(mine ? g : 0u);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&Q[cur], s);
+            if (mine) pending = -1;
+        }
+    }
+}
+
+__global__ void ehd_classify_kernel(const uint32_t* __restrict__ qsum, int B, int H, int W, int bs,
+                                    int nbx, int nby, int threshold, int32_t* __restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int nblk = nbx * nby;
+    if (t >= B * nblk) return;
+    int b = t / nblk, k = t - b * nblk;
+    int by = k / nbx, bx = k - by * nbx;
+    const uint32_t* q = qsum + (size_t)t * 4;
+    long long s1 = q[0], s2 = q[1], s3 = q[2], s4 = q[3];
+    long long hbq = (long long)(bs / 2) * (bs / 2);
+    long long e[5];
+    long long v = s1 - s2 + s3 - s4, h = s1 + s2 - s3 - s4, d45 = s1 - s4, d135 = s2 - s3,
+              nd = s1 - s2 - s3 + s4;
+    e[0] = v * v;
+    e[1] = h * h;
+    e[2] = 2 * d45 * d45;
+    e[3] = 2 * d135 * d135;
+    e[4] = 4 * nd * nd;
+    long long best = e[0];
+    int type = 0;
+    for (int i = 1; i < 5; ++i)
+        if (e[i] > best) {
+            best = e[i];
+            type = i;
+        }
+    int sub = (bx * bs * 4) / W + ((by * bs * 4) / H) * 4;
+    int32_t* o = out + (size_t)b * 96;
+    atomicAdd(&o[80 + sub], 1);
+    long long thr = (long long)threshold * hbq;
+    if (best >= thr * thr) atomicAdd(&o[sub * 5 + type], 1);
+}
+
+// ------------------------------------------------------------------------------ CSD
+struct HmmdTab {
+    int nsub;
+    int thr[6];
+    int nhue[5], nsum[5], off[5];
+};
+
+__device__ __forceinline__ int hmmd_cell(int b, int g, int r, const HmmdTab& T) {
+    int mx = max(max(r, g), b), mn = min(min(r, g), b);
+    int d = mx - mn, s2 = mx + mn;
+    int hue = 0;
+    if (d > 0) {
+        int num;
+        if (r == mx) num = 60 * (g - b);
+        else if (g == mx) num = 120 * d + 60 * (b - r);
+        else num = 240 * d + 60 * (r - g);
+        if (num < 0) num += 360 * d;
+        hue = (2 * num + d) / (2 * d);
+        if (hue >= 360) hue -= 360;
+    }
+    int sub = 0;
+    for (int i = 1; i < T.nsub; ++i) sub += (d >= T.thr[i]);
+    int lo = T.thr[sub];
+    int ihue = hue * T.nhue[sub] / 360;
+    int isum = (s2 - lo) * T.nsum[sub] / (2 * (256 - lo));
+    return T.off[sub] + ihue * T.nsum[sub] + isum;
+}
+
+__global__ __launch_bounds__(256) void hmmd_kernel(const uint8_t* __restrict__ img,
+                                                   uint8_t* __restrict__ out, long long npix,
+                                                   HmmdTab T) {
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * 256) {
+        const uint8_t* q = img + p * 3;
+        out[p] = (uint8_t)hmmd_cell(q[0], q[1], q[2], T);
+    }
+}
+
+constexpr int CS_W = 32, CS_H = 8, CS_PW = CS_W + 7, CS_PH = CS_H + 7;
+
+// one thread per window origin on the sub-sampled grid; 32 x 8 windows per workgroup
+__global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ img, int H, int W,
+                                                  int K, int nwx, int nwy, int nbins,
+                                                  int32_t* __restrict__ out, HmmdTab T) {
+    __shared__ uint8_t cell[CS_PH * CS_PW];
+    __shared__ uint32_t hist[256];
+    const int b = blockIdx.z;
+    const int u0 = blockIdx.x * CS_W, v0 = blockIdx.y * CS_H;
+    const uint8_t* im = img + (size_t)b * H * W * 3;
+    for (int i = threadIdx.x; i < 256; i += 256) hist[i] = 0;
+    for (int i = threadIdx.x; i < CS_PH * CS_PW; i += 256) {
+        int pv = i / CS_PW, pu = i - pv * CS_PW;
+        int u = u0 + pu, v = v0 + pv;
+        uint8_t c = 0;
+        if (u < nwx + 7 && v < nwy + 7) {
+            const uint8_t* q = im + ((size_t)(v * K) * W + (size_t)u * K) * 3;
+            c = (uint8_t)hmmd_cell(q[0], q[1], q[2], T);
+        }
+        cell[i] = c;
+    }
+    __syncthreads();
+    const int tu = threadIdx.x & 31, tv = threadIdx.x >> 5;
+    const bool valid = (u0 + tu < nwx) && (v0 + tv < nwy);
+    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
+#pragma unroll
+        for (int dv = 0; dv < 8; ++dv)
+#pragma unroll
+            for (int du = 0; du < 8; ++du) {
+                uint32_t c = cell[(tv + dv) * CS_PW + tu + du];
+                uint32_t bit = 1u << (c & 31u), wsel = c >> 5;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) m[w] |= (wsel == (uint32_t)w) ? bit : 0u;
+            }
+    }
+    // every colour present in a window counts once: count lanes per bit, one add per wave
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        uint32_t any = wave_or(m[w]);
+        while (any) {
+            int bit = __ffs((int)any) - 1;
+            any &= any - 1;
+            unsigned long long vote = __ballot((m[w] >> bit) & 1u);
+            if (lane == 0) atomicAdd(&hist[w * 32 + bit], (uint32_t)__popcll(vote));
+        }
+    }
+    __syncthreads();
+    int32_t* o = out + (size_t)b * (nbins + 1);
+    for (int i = threadIdx.x; i < nbins; i += 256)
+        if (hist[i]) atomicAdd(&o[i], (int32_t)hist[i]);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) o[nbins] = nwx * nwy;
+}
+
+int make_hmmd(int nbins, HmmdTab* T) {
+    static const int thr5[6] = {0, 6, 20, 60, 110, 256};
+    static const int thr4[5] = {0, 6, 60, 110, 256};
+    const int *nh, *ns;
+    static const int nh256[5] = {1, 4, 16, 16, 16}, ns256[5] = {32, 8, 4, 4, 4};
+    static const int nh128[5] = {1, 4, 8, 8, 8}, ns128[5] = {16, 4, 4, 4, 4};
+    static const int nh64[5] = {1, 4, 4, 8, 8}, ns64[5] = {8, 4, 4, 2, 1};
+    static const int nh32[4] = {1, 4, 4, 4}, ns32[4] = {8, 4, 1, 1};
+    *T = HmmdTab{};
+    switch (nbins) {
+        case 256: nh = nh256; ns = ns256; T->nsub = 5; break;
+        case 128: nh = nh128; ns = ns128; T->nsub = 5; break;
+        case 64: nh = nh64; ns = ns64; T->nsub = 5; break;
+        case 32: nh = nh32; ns = ns32; T->nsub = 4; break;
+        default: return imgan::fail(imgan::E_INVALID, "HMMD quantisation supports 32, 64, 128 or 256 cells");
+    }
+    int off = 0;
+    for (int i = 0; i < T->nsub; ++i) {
+        T->thr[i] = T->nsub == 5 ? thr5[i] : thr4[i];
+        T->nhue[i] = nh[i];
+        T->nsum[i] = ns[i];
+        T->off[i] = off;
+        off += nh[i] * ns[i];
+    }
+    T->thr[T->nsub] = 256;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t imgan_cld_scratch_bytes(int B) { return B < 1 ? 0 : (size_t)B * 64 * 4 * 8; }
+
+extern "C" int imgan_cld(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out, void* scratch,
+                         imgan_stream_t stream) {
+    IMGAN_REQUIRE(bgr && cld_out && scratch, "imgan_cld: null pointer");
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && B <= 65535, "imgan_cld: bad shape");
+    IMGAN_REQUIRE((long long)H * 8 < 0x7fffffffLL && (long long)W * 8 < 0x7fffffffLL, "imgan_cld: too large");
+    hipStream_t st = (hipStream_t)stream;
+    IMGAN_HIP(hipMemsetAsync(scratch, 0, imgan_cld_scratch_bytes(B), st));
+    long long npix = (long long)H * W;
+    dim3 grid((unsigned)imgan::cdiv(npix, 256 * 8), (unsigned)B);
+    hipLaunchKernelGGL(cld_sums_kernel, grid, dim3(256), 0, st, bgr, H, W,
+                       (unsigned long long*)scratch);
+    DctTable T;
+    for (int i = 0; i < 8; ++i) {
+        double s = i == 0 ? sqrt(0.125) : 0.5;
+        for (int j = 0; j < 8; ++j) T.c[i * 8 + j] = s * cos((M_PI / 8.0) * i * (j + 0.5));
+    }
+    hipLaunchKernelGGL(cld_finalise_kernel, dim3(imgan::cdiv(B * 3, 64)), dim3(64), 0, st,
+                       (const unsigned long long*)scratch, B, cld_out, T);
+    return imgan::check_launch("imgan_cld");
+}
+
+static int ehd_block_size(int H, int W) {
+    double temp = sqrt((double)W * H / 1100.0);
+    int bs = (int)(temp / 2) * 2;
+    return bs ? bs : 2;
+}
+
+extern "C" size_t imgan_ehd_scratch_bytes(int B, int H, int W) {
+    if (B < 1 || H < 1 || W < 1) return 0;
+    int bs = ehd_block_size(H, W);
+    size_t nb = (size_t)(W / bs) * (H / bs);
+    return imgan::align_up((size_t)B * (nb ? nb : 1) * 4 * 4, 256);
+}
+
+extern "C" int imgan_ehd(const uint8_t* bgr, int B, int H, int W, int32_t* ehd_out, void* scratch,
+                         imgan_stream_t stream) {
+    IMGAN_REQUIRE(bgr && ehd_out && scratch, "imgan_ehd: null pointer");
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && B <= 65535, "imgan_ehd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    int bs = ehd_block_size(H, W);
+    int nbx = W / bs, nby = H / bs;
+    // a quadrant sum must fit in 32 bits
+    IMGAN_REQUIRE((double)(bs / 2) * (bs / 2) * 255.0 < 4294967295.0, "imgan_ehd: image too large");
+    IMGAN_HIP(hipMemsetAsync(ehd_out, 0, (size_t)B * 96 * 4, st));
+    if (nbx == 0 || nby == 0) return 0;
+    IMGAN_HIP(hipMemsetAsync(scratch, 0, imgan_ehd_scratch_bytes(B, H, W), st));
+    long long npix = (long long)H * W;
+    dim3 grid((unsigned)imgan::cdiv(npix, 256 * 8), (unsigned)B);
+    hipLaunchKernelGGL(ehd_sums_kernel, grid, dim3(256), 0, st, bgr, H, W, bs, nbx, nby,
+                       (uint32_t*)scratch);
+    int total = B * nbx * nby;
+    hipLaunchKernelGGL(ehd_classify_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st,
+                       (const uint32_t*)scratch, B, H, W, bs, nbx, nby, 11, ehd_out);
+    return imgan::check_launch("imgan_ehd");
+}
+
+extern "C" int imgan_hmmd_quantise(const uint8_t* bgr, uint8_t* out, int64_t npix, int nbins,
+                                   imgan_stream_t stream) {
+    IMGAN_REQUIRE(bgr && out && npix >= 0, "imgan_hmmd_quantise: bad arguments");
+    HmmdTab T;
+    if (int rc = make_hmmd(nbins, &T)) return rc;
+    if (npix == 0) return 0;
+    int grid = (int)std::min<int64_t>(imgan::cdiv(npix, 256), 4096);
+    hipLaunchKernelGGL(hmmd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, bgr, out,
+                       (long long)npix, T);
+    return imgan::check_launch("hmmd_kernel");
+}
+
+extern "C" int imgan_csd(const uint8_t* bgr, int B, int H, int W, int nbins, int32_t* csd_out,
+                         imgan_stream_t stream) {
+    IMGAN_REQUIRE(bgr && csd_out, "imgan_csd: null pointer");
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && B <= 65535, "imgan_csd: bad shape");
+    HmmdTab T;
+    if (int rc = make_hmmd(nbins, &T)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    int p = (int)floor(0.5 * log2((double)W * H) - 8.0 + 0.5);
+    int K = 1 << (p > 0 ? p : 0);
+    int nwx = W >= 8 * K ? (W - 8 * K) / K + 1 : 0;
+    int nwy = H >= 8 * K ? (H - 8 * K) / K + 1 : 0;
+    IMGAN_HIP(hipMemsetAsync(csd_out, 0, (size_t)B * (nbins + 1) * 4, st));
+    if (nwx == 0 || nwy == 0) return 0;
+    dim3 grid((unsigned)imgan::cdiv(nwx, CS_W), (unsigned)imgan::cdiv(nwy, CS_H), (unsigned)B);
+    hipLaunchKernelGGL(csd_kernel, grid, dim3(256), 0, st, bgr, H, W, K, nwx, nwy, nbins, csd_out, T);
+    return imgan::check_launch("imgan_csd");
+}

@@ -1,0 +1,341 @@
+// Region adjacency graph: per-label colour sums + 8-connected adjacency (device), the
+// MST merge (host) and the relabel / paint passes (device).
+// Replaces scripts/rag_segmentation.py:27-48 (means), :50-74 (neighbours_regions),
+// :77-184 (find_edges .. concat_similar_regs).
+//
+// Device pass: one sweep over labels (4 B/px) + image (3 B/px).  Sums are aggregated per
+// wave before touching memory (labels are spatially coherent, so a wave sees a handful of
+// distinct labels): one 64-bit atomic per (wave, label, field).  Adjacent label pairs are
+// only produced on region borders (a few % of the pixels) and go into a per-image
+// open-addressed hash set with a read-before-CAS probe, so the common "already present"
+// case costs one cached load.
+#include "common.h"
+#include "../../include/imgan.h"
+#include <algorithm>
+#include <math.h>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t hash64(unsigned long long k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+__device__ void edge_insert(unsigned long long* tab, unsigned long long mask, int a, int b,
+                            int* overflow) {
+    int u = min(a, b), v = max(a, b);
+    unsigned long long key = ((unsigned long long)(u + 1) << 32) | (unsigned long long)(v + 1);
+    unsigned long long h = hash64(key) & mask;
+    for (unsigned long long probe = 0; probe <= mask; ++probe) {
+        unsigned long long cur = tab[h];
+        if (cur == key) return;
+        if (cur == 0ull) {
+            unsigned long long old = atomicCAS(&tab[h], 0ull, key);
+            if (old == 0ull || old == key) return;
+        }
+        h = (h + 1) & mask;
+    }
+    *overflow = 1;
+}
+
+// one thread per pixel, rows of the image; block = 256 consecutive pixels of one image
+__global__ __launch_bounds__(256) void rag_accumulate_kernel(
+    const uint8_t* __restrict__ img, const int32_t* __restrict__ labels, int H, int W, int K,
+    unsigned long long* __restrict__ sums, unsigned long long* __restrict__ edges,
+    unsigned long long edge_mask, int* __restrict__ overflow) {
+    const int b = blockIdx.y;
+    const long long npix = (long long)H * W;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int32_t* lab = labels + (size_t)b * npix;
+    const uint8_t* im = img + (size_t)b * npix * 3;
+    unsigned long long* S = sums + (size_t)b * K * 4;
+    unsigned long long* E = edges ? edges + (size_t)b * (edge_mask + 1) : nullptr;
+
+    int l = -1;
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    int x = 0, y = 0;
+    if (p < npix) {
+        l = lab[p];
+        y = (int)(p / W);
+        x = (int)(p - (long long)y * W);
+        if (l >= 0) {
+            const uint8_t* q = im + p * 3;
+            c0 = q[0];
+            c1 = q[1];
+            c2 = q[2];
+        }
+    }
+    // ---- per-label sums, aggregated over the wave
+    int pending = (l >= 0 && l < K) ? l : -1;
+    while (true) {
+        unsigned long long act = __ballot(pending >= 0);
+        if (act == 0ull) break;
+        int leader = __ffsll((long long)act) - 1;
+        int cur = __shfl(pending, leader);
+        bool mine = (pending == cur);
+        uint32_t w0 = mine ? (c0 | (c1 << 16)) : 0u;      // <= 64 * 255 per half: no overflow
+        uint32_t w1 = mine ? (c2 | (1u << 16)) : 0u;
+        w0 = wave_sum(w0);
+        w1 = wave_sum(w1);
+        if ((int)(threadIdx.x & 63) == leader) {
+            unsigned long long* s = S + (size_t)cur * 4;
+            atomicAdd(&s[0], (unsigned long long)(w0 & 0xffffu));
+            atomicAdd(&s[1], (unsigned long long)(w0 >> 16));
+            atomicAdd(&s[2], (unsigned long long)(w1 & 0xffffu));
+            atomicAdd(&s[3], (unsigned long long)(w1 >> 16));
+        }
+        if (mine) pending = -1;
+    }
+    // ---- adjacency: E, S, SE, SW neighbours (each unordered 8-neighbour pair once)
+    if (E && l >= 0) {
+        int last = -1;
+        const bool hasS = (y + 1 < H);
+        if (x + 1 < W) {
+            int r = lab[p + 1];
+            if (r >= 0 && r != l) {
+                edge_insert(E, edge_mask, l, r, overflow + b);
+                last = r;
+            }
+            if (hasS) {
+                int r2 = lab[p + W + 1];
+                if (r2 >= 0 && r2 != l && r2 != last) {
+                    edge_insert(E, edge_mask, l, r2, overflow + b);
+                    last = r2;
+                }
+            }
+        }
+        if (hasS) {
+            int r = lab[p + W];
+            if (r >= 0 && r != l && r != last) {
+                edge_insert(E, edge_mask, l, r, overflow + b);
+                last = r;
+            }
+            if (x > 0) {
+                int r2 = lab[p + W - 1];
+                if (r2 >= 0 && r2 != l && r2 != last) edge_insert(E, edge_mask, l, r2, overflow + b);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void relabel_kernel(const int32_t* __restrict__ labels,
+                                                      const int32_t* __restrict__ lut,
+                                                      int32_t* __restrict__ out, long long npix,
+                                                      int K) {
+    const int b = blockIdx.y;
+    const int32_t* L = lut + (size_t)b * K;
+    const int32_t* src = labels + (size_t)b * npix;
+    int32_t* dst = out + (size_t)b * npix;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * 256) {
+        int l = src[p];
+        dst[p] = (l >= 0 && l < K) ? L[l] : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void paint_kernel(uint8_t* __restrict__ img,
+                                                    const int32_t* __restrict__ labels,
+                                                    const uint8_t* __restrict__ means,
+                                                    long long npix, int K) {
+    const int b = blockIdx.y;
+    const uint8_t* M = means + (size_t)b * K * 3;
+    const int32_t* src = labels + (size_t)b * npix;
+    uint8_t* dst = img + (size_t)b * npix * 3;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * 256) {
+        int l = src[p];
+        if (l >= 0 && l < K) {
+            dst[3 * p] = M[3 * l];
+            dst[3 * p + 1] = M[3 * l + 1];
+            dst[3 * p + 2] = M[3 * l + 2];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host merge
+struct Sets {
+    // list-of-sets semantics of rag_segmentation.py:117-130: union(v1, v2) appends the set
+    // of v2 to the set of v1 and removes v2's entry; a set keeps the list slot ("anchor")
+    // of the set it was merged into.
+    std::vector<int> parent, anchor, head, tail, next;
+    int alive;
+    explicit Sets(int K) : parent(K), anchor(K), head(K), tail(K), next(K, -1), alive(K) {
+        std::iota(parent.begin(), parent.end(), 0);
+        std::iota(anchor.begin(), anchor.end(), 0);
+        std::iota(head.begin(), head.end(), 0);
+        std::iota(tail.begin(), tail.end(), 0);
+    }
+    int find(int v) {
+        int r = v;
+        while (parent[r] != r) r = parent[r];
+        while (parent[v] != r) {
+            int nx = parent[v];
+            parent[v] = r;
+            v = nx;
+        }
+        return r;
+    }
+    bool unite(int v1, int v2) {
+        int r1 = find(v1), r2 = find(v2);
+        if (r1 == r2) return false;
+        parent[r2] = r1;                 // r1 keeps its anchor and member order
+        next[tail[r1]] = head[r2];
+        tail[r1] = tail[r2];
+        --alive;
+        return true;
+    }
+};
+
+}  // namespace
+
+extern "C" int imgan_rag_accumulate(const uint8_t* img, const int32_t* labels, int B, int H, int W,
+                                    int K, uint64_t* sums, uint64_t* edges, int64_t edge_cap,
+                                    int32_t* overflow, imgan_stream_t stream) {
+    IMGAN_REQUIRE(img && labels && sums, "imgan_rag_accumulate: null pointer");
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && K >= 1, "imgan_rag_accumulate: bad shape");
+    IMGAN_REQUIRE(B <= 65535, "imgan_rag_accumulate: batch > 65535, split the call");
+    if (edges) {
+        IMGAN_REQUIRE(edge_cap >= 2 && (edge_cap & (edge_cap - 1)) == 0,
+                      "imgan_rag_accumulate: edge_cap must be a power of two");
+        IMGAN_REQUIRE(overflow != nullptr, "imgan_rag_accumulate: overflow flags required");
+    }
+    long long npix = (long long)H * W;
+    dim3 grid((unsigned)imgan::cdiv(npix, 256), (unsigned)B);
+    hipLaunchKernelGGL(rag_accumulate_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, labels,
+                       H, W, K, (unsigned long long*)sums, (unsigned long long*)edges,
+                       (unsigned long long)(edges ? edge_cap - 1 : 0), overflow);
+    return imgan::check_launch("rag_accumulate_kernel");
+}
+
+extern "C" int imgan_relabel_lut(const int32_t* labels, const int32_t* lut, int32_t* out, int B,
+                                 int64_t npix, int K, imgan_stream_t stream) {
+    IMGAN_REQUIRE(labels && lut && out, "imgan_relabel_lut: null pointer");
+    IMGAN_REQUIRE(B >= 1 && npix >= 1 && K >= 1 && B <= 65535, "imgan_relabel_lut: bad shape");
+    dim3 grid((unsigned)std::min<int64_t>(imgan::cdiv(npix, 256), 8192), (unsigned)B);
+    hipLaunchKernelGGL(relabel_kernel, grid, dim3(256), 0, (hipStream_t)stream, labels, lut, out,
+                       (long long)npix, K);
+    return imgan::check_launch("relabel_kernel");
+}
+
+extern "C" int imgan_paint_means(uint8_t* img, const int32_t* labels, const uint8_t* means_u8,
+                                 int B, int64_t npix, int K, imgan_stream_t stream) {
+    IMGAN_REQUIRE(img && labels && means_u8, "imgan_paint_means: null pointer");
+    IMGAN_REQUIRE(B >= 1 && npix >= 1 && K >= 1 && B <= 65535, "imgan_paint_means: bad shape");
+    dim3 grid((unsigned)std::min<int64_t>(imgan::cdiv(npix, 256), 8192), (unsigned)B);
+    hipLaunchKernelGGL(paint_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, labels,
+                       means_u8, (long long)npix, K);
+    return imgan::check_launch("paint_kernel");
+}
+
+extern "C" int imgan_rag_merge_host(const int32_t* means, const double* weights, int K,
+                                    const int32_t* edges_uv, int64_t E, double c_factor,
+                                    int32_t* lut_out, int32_t* mst_out, double* mst_w_out,
+                                    int32_t* n_mst_out, int32_t* members_out,
+                                    int32_t* set_offsets_out, int32_t* n_sets_out) {
+    IMGAN_REQUIRE(lut_out && n_mst_out && n_sets_out, "imgan_rag_merge_host: null pointer");
+    IMGAN_REQUIRE((means != nullptr) != (weights != nullptr),
+                  "imgan_rag_merge_host: give either means or weights");
+    IMGAN_REQUIRE(K >= 1 && E >= 0 && (E == 0 || edges_uv), "imgan_rag_merge_host: bad sizes");
+    struct Edge {
+        int u, v;
+        long long w2;      // exact squared weight (means mode)
+        double w;          // weight as the reference sees it
+    };
+    std::vector<Edge> ed;
+    ed.reserve((size_t)E);
+    for (int64_t i = 0; i < E; ++i) {
+        int u = edges_uv[2 * i], v = edges_uv[2 * i + 1];
+        if (u < 0 || v < 0 || u >= K || v >= K || u == v)
+            return imgan::fail(imgan::E_INVALID, "imgan_rag_merge_host: edge endpoint out of range");
+        if (means) {
+            if (u > v) std::swap(u, v);
+            long long d0 = means[3 * u] - means[3 * v], d1 = means[3 * u + 1] - means[3 * v + 1],
+                      d2 = means[3 * u + 2] - means[3 * v + 2];
+            long long w2 = d0 * d0 + d1 * d1 + d2 * d2;          // metric_methods.py:5-6, squared
+            ed.push_back({u, v, w2, sqrt((double)w2)});
+        } else {
+            ed.push_back({u, v, 0, weights[i]});
+        }
+    }
+    if (means) {
+        // canonical discovery order (:93-99 with ascending dict / set order): lexicographic (u,v)
+        std::sort(ed.begin(), ed.end(), [](const Edge& a, const Edge& b) {
+            return a.u != b.u ? a.u < b.u : a.v < b.v;
+        });
+        ed.erase(std::unique(ed.begin(), ed.end(),
+                             [](const Edge& a, const Edge& b) { return a.u == b.u && a.v == b.v; }),
+                 ed.end());
+        // :103-114 stable insertion sort by weight (sqrt is monotone: sort by the exact square)
+        std::stable_sort(ed.begin(), ed.end(),
+                         [](const Edge& a, const Edge& b) { return a.w2 < b.w2; });
+    } else {
+        // weights mode: edges arrive in the caller's discovery order, already de-duplicated
+        std::stable_sort(ed.begin(), ed.end(), [](const Edge& a, const Edge& b) { return a.w < b.w; });
+    }
+
+    // :132-145 first Kruskal
+    std::vector<Edge> mst;
+    {
+        Sets s(K);
+        for (size_t i = 0; i < ed.size() && s.alive > 1; ++i)
+            if (s.unite(ed[i].u, ed[i].v)) mst.push_back(ed[i]);
+    }
+    // :163-170 keep edge i iff w_i < mean(others) + c * std(others), population std
+    std::vector<Edge> kept;
+    const size_t m = mst.size();
+    if (m >= 2) {
+        long double T = 0.0L, Q = 0.0L;
+        for (const Edge& e : mst) {
+            T += (long double)e.w;
+            Q += means ? (long double)e.w2 : (long double)e.w * (long double)e.w;
+        }
+        for (const Edge& e : mst) {
+            long double w = (long double)e.w;
+            long double q = means ? (long double)e.w2 : w * w;
+            long double mean = (T - w) / (long double)(m - 1);
+            long double var = (Q - q) / (long double)(m - 1) - mean * mean;
+            if (var < 0.0L) var = 0.0L;
+            if (e.w < (double)(mean + (long double)c_factor * sqrtl(var))) kept.push_back(e);
+        }
+    }   // m == 1: mean of an empty list is NaN -> the edge is dropped (:166-168)
+
+    // :173 second Kruskal from singletons, :175-182 ids in surviving-list order
+    Sets s(K);
+    int n_mst = 0;
+    for (const Edge& e : kept)
+        if (s.alive > 1 && s.unite(e.u, e.v)) {
+            if (mst_out) {
+                mst_out[2 * n_mst] = e.u;
+                mst_out[2 * n_mst + 1] = e.v;
+            }
+            if (mst_w_out) mst_w_out[n_mst] = e.w;
+            ++n_mst;
+        }
+    *n_mst_out = n_mst;
+    int id = 0, pos = 0;
+    for (int v = 0; v < K; ++v) {
+        if (s.find(v) != v) continue;          // surviving sets sit at their anchor's slot
+        ++id;
+        if (set_offsets_out) set_offsets_out[id - 1] = pos;
+        for (int e = s.head[v]; e >= 0; e = s.next[e]) {
+            lut_out[e] = id;
+            if (members_out) members_out[pos] = e;
+            ++pos;
+        }
+    }
+    if (set_offsets_out) set_offsets_out[id] = pos;
+    *n_sets_out = id;
+    return 0;
+}

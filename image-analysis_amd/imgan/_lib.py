@@ -36,15 +36,17 @@ SIGNATURES = {
     "imgan_slic_run": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "imgan_rag_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-                                     c_void_p, c_i64, c_void_p]),
-    "imgan_rag_merge_host": (c_int, [c_void_p, c_int, c_void_p, c_i64, c_double, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_void_p]),
+                                     c_void_p, c_i64, c_void_p, c_void_p]),
+    "imgan_rag_merge_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_i64, c_double,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
     "imgan_relabel_lut": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p]),
     "imgan_paint_means": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p]),
     "imgan_cc_label": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "imgan_dcd_state_bytes": (c_size_t, [c_int, c_int, c_int]),
     "imgan_dcd_kmeans_round": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "imgan_dcd_rounds": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_dcd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p]),
     "imgan_cld": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

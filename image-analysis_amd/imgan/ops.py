@@ -142,3 +142,239 @@ class SlicPlan(object):
                                  float(colour_weight), int(num_iter), _ptr(self.centres),
                                  _ptr(self.labels), _ptr(self.workspace), _stream()))
         return self.labels, self.centres
+
+
+# ------------------------------------------------------------------------ RAG
+
+def _pow2_at_least(x):
+    p = 2
+    while p < x:
+        p <<= 1
+    return p
+
+
+def rag_accumulate(img, labels, K, want_edges=True, edge_cap=None):
+    """Per-label colour sums + 8-connected adjacency (rag_segmentation.py:38-74).
+
+    img: u8 [B,H,W,3] (any 3-channel image), labels: int32 [B,H,W].
+    Returns (sums uint64-as-int64 [B,K,4] = c0,c1,c2,count, edges [list per image of int32 [E,2]
+    arrays with u < v, lexicographically sorted] or None)."""
+    _require_gpu()
+    img = as_batch(_dev(img, torch.uint8, "img"))
+    if labels.dim() == 2:
+        labels = labels.unsqueeze(0)
+    _dev(labels, torch.int32, "labels")
+    B, H, W, _ = img.shape
+    if tuple(labels.shape) != (B, H, W):
+        raise ValueError("labels shape %s does not match image %s" % (tuple(labels.shape), (B, H, W)))
+    sums = torch.zeros((B, K, 4), dtype=torch.int64, device=img.device)
+    if not want_edges:
+        check(lib.imgan_rag_accumulate(_ptr(img), _ptr(labels), B, H, W, int(K), _ptr(sums), None,
+                                       0, None, _stream()))
+        return sums, None
+    cap = edge_cap or _pow2_at_least(16 * max(int(K), 64))
+    while True:
+        table = torch.zeros((B, cap), dtype=torch.int64, device=img.device)
+        overflow = torch.zeros(B, dtype=torch.int32, device=img.device)
+        sums.zero_()
+        check(lib.imgan_rag_accumulate(_ptr(img), _ptr(labels), B, H, W, int(K), _ptr(sums),
+                                       _ptr(table), cap, _ptr(overflow), _stream()))
+        if int(overflow.max().item()) == 0:
+            break
+        cap *= 4                                     # pathological adjacency: retry larger
+    edges = []
+    for b in range(B):
+        keys = table[b][table[b] != 0]
+        keys, _ = torch.sort(keys)                   # (u+1)<<32 | (v+1): lexicographic (u, v)
+        u = (keys >> 32) - 1
+        v = (keys & 0xffffffff) - 1
+        edges.append(torch.stack([u, v], dim=1).to(torch.int32).cpu().numpy())
+    return sums, edges
+
+
+def rag_merge_host(K, edges_uv, c_factor, means=None, weights=None):
+    """rag_segmentation.py:77-184 on the host (C++ in the library).
+    Either means (int [K,3]; canonical edge order) or weights (float [E]; edges in discovery
+    order).  Returns dict(lut, mst, mst_w, sets)."""
+    edges_uv = np.ascontiguousarray(edges_uv, dtype=np.int32).reshape(-1, 2)
+    E = edges_uv.shape[0]
+    if means is not None:
+        means = np.ascontiguousarray(means, dtype=np.int32)
+    if weights is not None:
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+    lut = np.zeros(K, dtype=np.int32)
+    mst = np.zeros((max(K, 1), 2), dtype=np.int32)
+    w = np.zeros(max(K, 1), dtype=np.float64)
+    members = np.zeros(K, dtype=np.int32)
+    offsets = np.zeros(K + 1, dtype=np.int32)
+    n_mst, n_sets = ctypes.c_int32(), ctypes.c_int32()
+    if (means is None) == (weights is None):
+        raise ValueError("give either means or weights")
+    if weights is not None and weights.shape[0] != E:
+        raise ValueError("one weight per edge expected")
+    if weights is not None and E == 0:
+        weights = np.zeros(1, dtype=np.float64)       # keeps the pointer non-NULL (mode switch)
+    check(lib.imgan_rag_merge_host(means.ctypes.data if means is not None else None,
+                                   weights.ctypes.data if weights is not None else None,
+                                   int(K), edges_uv.ctypes.data if E else None, E, float(c_factor),
+                                   lut.ctypes.data, mst.ctypes.data, w.ctypes.data,
+                                   ctypes.byref(n_mst), members.ctypes.data, offsets.ctypes.data,
+                                   ctypes.byref(n_sets)))
+    ns = n_sets.value
+    sets = [members[offsets[i]:offsets[i + 1]].tolist() for i in range(ns)]
+    return {"lut": lut, "mst": mst[:n_mst.value].copy(), "mst_w": w[:n_mst.value].copy(),
+            "sets": sets}
+
+
+def relabel(labels, lut):
+    """out[p] = lut[labels[p]], labels < 0 -> 0 (rag_segmentation.py:175-182)."""
+    _require_gpu()
+    if labels.dim() == 2:
+        labels = labels.unsqueeze(0)
+    _dev(labels, torch.int32, "labels")
+    if lut.dim() == 1:
+        lut = lut.unsqueeze(0)
+    _dev(lut, torch.int32, "lut")
+    B = labels.shape[0]
+    out = torch.empty_like(labels)
+    check(lib.imgan_relabel_lut(_ptr(labels), _ptr(lut), _ptr(out), B, labels[0].numel(),
+                                lut.shape[1], _stream()))
+    return out
+
+
+def paint_means(img, labels, means_u8):
+    """img[labels == c] = means[c] in place (rag_segmentation.py:34,46)."""
+    _require_gpu()
+    imgb = as_batch(_dev(img, torch.uint8, "img"))
+    if labels.dim() == 2:
+        labels = labels.unsqueeze(0)
+    if means_u8.dim() == 2:
+        means_u8 = means_u8.unsqueeze(0)
+    _dev(labels, torch.int32, "labels")
+    _dev(means_u8, torch.uint8, "means")
+    check(lib.imgan_paint_means(_ptr(imgb), _ptr(labels), _ptr(means_u8), imgb.shape[0],
+                                labels[0].numel(), means_u8.shape[1], _stream()))
+    return img
+
+
+# ------------------------------------------------------------------------ CC / DCD
+
+def cc_label(values):
+    """8-connected components of equal non-negative values; returns root index per pixel."""
+    _require_gpu()
+    if values.dim() == 2:
+        values = values.unsqueeze(0)
+    _dev(values, torch.int32, "values")
+    B, H, W = values.shape
+    roots = torch.empty_like(values)
+    check(lib.imgan_cc_label(_ptr(values), _ptr(roots), B, H, W, _stream()))
+    return roots
+
+
+class DcdPlan(object):
+    """Dominant colours of every segment of a label map (mpeg7Descriptors.py:76-130)."""
+
+    def __init__(self, B, H, W, nseg, k):
+        _require_gpu()
+        self.B, self.H, self.W, self.nseg, self.k = int(B), int(H), int(W), int(nseg), int(k)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.state = torch.zeros(lib.imgan_dcd_state_bytes(self.B, self.nseg, self.k),
+                                 dtype=torch.uint8, device=dev)
+        self.assign = torch.empty((self.B, self.H, self.W), dtype=torch.uint8, device=dev)
+        self.active = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.stats = torch.empty((self.B, self.nseg, self.k, 8), dtype=torch.int64, device=dev)
+        self.scratch = None
+        self.rounds_run = 0
+
+    def kmeans(self, lab, labels, centres, max_rounds=1000, check_every=1):
+        """Runs Lloyd rounds until every segment met the reference's stop rule.
+        centres: float32 [B,nseg,k,3], updated in place."""
+        lab = as_batch(_dev(lab, torch.uint8, "lab"))
+        if labels.dim() == 2:
+            labels = labels.unsqueeze(0)
+        _dev(labels, torch.int32, "labels")
+        _dev(centres, torch.float32, "centres")
+        if tuple(centres.shape) != (self.B, self.nseg, self.k, 3):
+            raise ValueError("centres must be [B,nseg,k,3]")
+        self.state.zero_()
+        r = 0
+        while r < max_rounds:
+            check(lib.imgan_dcd_kmeans_round(_ptr(lab), _ptr(labels), self.B, self.H, self.W,
+                                             self.nseg, self.k, _ptr(centres), _ptr(self.assign),
+                                             _ptr(self.state), 1 if r == 0 else 0,
+                                             _ptr(self.active), _stream()))
+            r += 1
+            if r % check_every == 0 and int(self.active.item()) == 0:
+                break
+        self.rounds_run = r
+        return centres, self.assign
+
+    def rounds(self):
+        rounds = torch.empty((self.B, self.nseg), dtype=torch.int32, device=self.state.device)
+        done = torch.empty_like(rounds)
+        check(lib.imgan_dcd_rounds(_ptr(self.state), self.B, self.nseg, self.k, _ptr(rounds),
+                                   _ptr(done), _stream()))
+        return rounds, done
+
+    def statistics(self, lab, labels):
+        """uint64 [B,nseg,k,8]: count, sum c0..c2, sum of squares c0..c2, largest component."""
+        lab = as_batch(_dev(lab, torch.uint8, "lab"))
+        if labels.dim() == 2:
+            labels = labels.unsqueeze(0)
+        if self.scratch is None:
+            self.scratch = torch.empty((3, self.B, self.H, self.W), dtype=torch.int32,
+                                       device=self.state.device)
+        check(lib.imgan_dcd_stats(_ptr(lab), _ptr(labels), _ptr(self.assign), self.B, self.H,
+                                  self.W, self.nseg, self.k, _ptr(self.stats), _ptr(self.scratch),
+                                  _stream()))
+        return self.stats
+
+
+# ------------------------------------------------------------------------ CLD / EHD / CSD
+
+class DescriptorPlan(object):
+    """Whole-image MPEG-7 colour layout, edge histogram and colour structure for a batch."""
+
+    def __init__(self, B, H, W, nbins=256):
+        _require_gpu()
+        self.B, self.H, self.W, self.nbins = int(B), int(H), int(W), int(nbins)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.cld = torch.empty((self.B, 3, 64), dtype=torch.int32, device=dev)
+        self.ehd = torch.empty((self.B, 96), dtype=torch.int32, device=dev)
+        self.csd = torch.empty((self.B, self.nbins + 1), dtype=torch.int32, device=dev)
+        self.cld_scratch = torch.empty(max(lib.imgan_cld_scratch_bytes(self.B), 8),
+                                       dtype=torch.uint8, device=dev)
+        self.ehd_scratch = torch.empty(max(lib.imgan_ehd_scratch_bytes(self.B, self.H, self.W), 8),
+                                       dtype=torch.uint8, device=dev)
+
+    def _img(self, bgr):
+        bgr = as_batch(_dev(bgr, torch.uint8, "bgr"))
+        if tuple(bgr.shape) != (self.B, self.H, self.W, 3):
+            raise ValueError("image batch does not match the plan")
+        return bgr
+
+    def colour_layout(self, bgr):
+        bgr = self._img(bgr)
+        check(lib.imgan_cld(_ptr(bgr), self.B, self.H, self.W, _ptr(self.cld),
+                            _ptr(self.cld_scratch), _stream()))
+        return self.cld
+
+    def edge_histogram(self, bgr):
+        bgr = self._img(bgr)
+        check(lib.imgan_ehd(_ptr(bgr), self.B, self.H, self.W, _ptr(self.ehd),
+                            _ptr(self.ehd_scratch), _stream()))
+        return self.ehd
+
+    def colour_structure(self, bgr):
+        bgr = self._img(bgr)
+        check(lib.imgan_csd(_ptr(bgr), self.B, self.H, self.W, self.nbins, _ptr(self.csd),
+                            _stream()))
+        return self.csd
+
+
+def hmmd_quantise(bgr, nbins=256):
+    _require_gpu()
+    _dev(bgr, torch.uint8, "bgr")
+    out = torch.empty(bgr.shape[:-1], dtype=torch.uint8, device=bgr.device)
+    check(lib.imgan_hmmd_quantise(_ptr(bgr), _ptr(out), bgr.numel() // 3, int(nbins), _stream()))
+    return out

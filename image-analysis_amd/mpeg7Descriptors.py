@@ -1,0 +1,216 @@
+"""Drop-in replacement for scripts/mpeg7Descriptors.py (class MPEG7Descriptors, :18-365).
+
+Built in this round (HIP kernels through libimgan_hip.so):
+  * dominant colour per segment          -- mpeg7Descriptors.py:76-141
+  * colour layout, edge histogram, colour structure -- additive methods; the reference does
+    not have them, they follow ISO/IEC 15938-3 as defined in DESIGN.md.
+Not built yet (SURVEY.md 8f "next" rows, raise NotImplementedError): homogeneous texture
+(:277-365) and region shape / ART (:144-275).
+
+Deviations of dominant colour from the reference, all stated in DESIGN.md:
+  * the reference samples the initial centres with an unseeded random.sample (:79); here the
+    sample comes from `random.Random(seed)` (seed=None keeps it non-deterministic) or from
+    explicit `init` indices, so a run can be reproduced;
+  * an empty cluster keeps its centre instead of being re-sampled at random (:101);
+  * spatial coherence uses true 8-connected components; the reference clamps the
+    neighbourhood at 255 (:52,:54), which is only correct for images up to 255 x 255.
+"""
+import random
+
+import numpy as np
+import torch
+
+from imgan import ops
+
+default_wres = 320
+gabor_radial = 5
+gabor_angular = 6
+
+
+class MPEG7Descriptors(object):
+
+    def __init__(self, clusters, image, seed=None):
+        # mpeg7Descriptors.py:20-26
+        if not isinstance(image, np.ndarray):
+            raise ValueError("Image value is None. Probably not loaded correctly!")
+        self.image_rgb = image
+        self._dev_bgr = torch.from_numpy(np.ascontiguousarray(image)).cuda()
+        self._dev_lab = ops.bgr2lab(self._dev_bgr)
+        self.image_lab = self._dev_lab.cpu().numpy()
+        self.image_gray = ops.bgr2gray(self._dev_bgr).cpu().numpy()
+        self.clusters = clusters
+        self.segments = set(clusters.flatten())
+        self.segments.discard(-1)
+        self._rng = random.Random(seed)
+        self.dcd_rounds = {}
+
+    # ------------------------------------------------------------------ helpers
+    def segment_generator(self, one_dim=True):
+        """mpeg7Descriptors.py:28-38: the image with every OTHER segment zeroed."""
+        seg_mask = np.isin(self.clusters, list(self.segments))
+        for segment_idx in self.segments:
+            new_image = self.image_gray.copy() if one_dim else self.image_rgb.copy()
+            new_image[seg_mask & (self.clusters != segment_idx)] = 0
+            yield new_image, segment_idx
+
+    def _segment_index_map(self):
+        segs = sorted(self.segments)
+        lut = {s: i for i, s in enumerate(segs)}
+        flat = self.clusters.ravel()
+        idx = np.full(flat.shape, -1, dtype=np.int32)
+        for s, i in lut.items():
+            idx[flat == s] = i
+        return segs, idx.reshape(self.clusters.shape)
+
+    def _features(self, stats, centres, nseg_pixels):
+        """stats: int [k,8]; centres float32 [k,3] -> {j: [mean, var, percentage, coherence]}."""
+        out = {}
+        for j in range(stats.shape[0]):
+            n = int(stats[j, 0])
+            mean = [float(v) for v in centres[j]]
+            if n == 0:
+                out[j] = [mean, [float("nan")] * 3, 0.0, 0.0]
+                continue
+            var = []
+            for c in range(3):
+                sx, sxx = int(stats[j, 1 + c]), int(stats[j, 4 + c])
+                var.append((n * sxx - sx * sx) / float(n * n))      # exact integers, one rounding
+            out[j] = [mean, var, n / float(nseg_pixels), int(stats[j, 7]) / float(n)]
+        return out
+
+    def _run_dcd(self, label_map, nseg, k, centres):
+        H, W = label_map.shape
+        plan = ops.DcdPlan(1, H, W, nseg, k)
+        dev_labels = torch.from_numpy(np.ascontiguousarray(label_map)).cuda().unsqueeze(0)
+        dev_centres = torch.from_numpy(np.ascontiguousarray(centres, dtype=np.float32)).cuda()
+        plan.kmeans(self._dev_lab, dev_labels, dev_centres.view(1, nseg, k, 3))
+        stats = plan.statistics(self._dev_lab, dev_labels)[0].cpu().numpy()
+        rounds, _ = plan.rounds()
+        return stats, dev_centres.cpu().numpy().reshape(nseg, k, 3), rounds[0].cpu().numpy()
+
+    # ------------------------------------------------------------------ dominant colour
+    def dominant_colour(self, num_dominant, segment, seg_idxs, init=None):
+        """mpeg7Descriptors.py:76-130 for one segment.
+        segment: N x 3 Lab points, seg_idxs: N x 2 (row, col); init: optional N-indices."""
+        segment = np.asarray(segment)
+        seg_idxs = np.asarray(seg_idxs)
+        if init is None:
+            init = self._rng.sample(range(len(segment)), num_dominant)   # ValueError if N < k (:79)
+        label_map = np.full(self.clusters.shape, -1, dtype=np.int32)
+        label_map[seg_idxs[:, 0], seg_idxs[:, 1]] = 0
+        centres = segment[np.asarray(init)].astype(np.float32).reshape(1, num_dominant, 3)
+        stats, cen, rounds = self._run_dcd(label_map, 1, num_dominant, centres)
+        return self._features(stats[0], cen[0], len(segment))
+
+    def mpeg7_dominant_colours(self, max_cols, init=None):
+        """mpeg7Descriptors.py:132-141: {segment: {j: [mean, var, percentage, coherence]}}.
+        init: optional {segment: k point indices in raster order within the segment}."""
+        segs, label_map = self._segment_index_map()
+        nseg = len(segs)
+        order = np.argsort(label_map.ravel(), kind="stable")
+        counts = np.bincount(label_map.ravel()[label_map.ravel() >= 0], minlength=nseg)
+        starts = np.concatenate([[0], np.cumsum(counts)]) + int((label_map < 0).sum())
+        lab_flat = self.image_lab.reshape(-1, 3)
+        centres = np.zeros((nseg, max_cols, 3), dtype=np.float32)
+        for i, seg in enumerate(segs):
+            n = int(counts[i])
+            if init is not None:
+                pick = list(init[int(seg)])
+            else:
+                pick = self._rng.sample(range(n), max_cols)              # ValueError if n < k
+            if len(pick) != max_cols or (n and max(pick) >= n):
+                raise ValueError("Sample larger than population or is negative")
+            centres[i] = lab_flat[order[starts[i] + np.asarray(pick)]]
+        stats, cen, rounds = self._run_dcd(label_map, nseg, max_cols, centres)
+        dcd_per_seg = {}
+        for i, seg in enumerate(segs):
+            dcd_per_seg[int(seg)] = self._features(stats[i], cen[i], int(counts[i]))
+            self.dcd_rounds[int(seg)] = int(rounds[i])
+        return dcd_per_seg
+
+    # ------------------------------------------------------------------ MPEG-7 additions
+    def _plan(self):
+        H, W = self.image_rgb.shape[:2]
+        return ops.DescriptorPlan(1, H, W)
+
+    def mpeg7_colour_layout(self, num_y=6, num_c=3):
+        """ISO/IEC 15938-3 colour layout of the whole image: num_y Y + num_c Cb + num_c Cr
+        quantised DCT coefficients (zig-zag order)."""
+        q = self._plan().colour_layout(self._dev_bgr)[0].cpu().numpy()
+        return [int(v) for v in np.concatenate([q[0, :num_y], q[1, :num_c], q[2, :num_c]])]
+
+    def mpeg7_edge_histogram(self, quantised=True):
+        """ISO/IEC 15938-3 edge histogram: 80 bins (16 sub-images x 5 edge types)."""
+        o = self._plan().edge_histogram(self._dev_bgr)[0].cpu().numpy()
+        counts, nblk = o[:80], o[80:]
+        if not quantised:
+            return [int(v) for v in counts], [int(v) for v in nblk]
+        return ehd_quantise(counts, nblk)
+
+    def mpeg7_colour_structure(self, nbins=256, quantised=True):
+        """ISO/IEC 15938-3 colour structure histogram over HMMD cells."""
+        H, W = self.image_rgb.shape[:2]
+        o = ops.DescriptorPlan(1, H, W, nbins).colour_structure(self._dev_bgr)[0].cpu().numpy()
+        hist, nwin = o[:nbins], int(o[nbins])
+        if not quantised:
+            return [int(v) for v in hist], nwin
+        return csd_quantise(hist, nwin)
+
+    # ------------------------------------------------------------------ next rows (8f)
+    def mpeg7_homogeneus_texture(self):
+        raise NotImplementedError("homogeneous texture (mpeg7Descriptors.py:277-365) is a "
+                                  "later row of the build plan (SURVEY.md 8f); not built yet")
+
+    def mpeg7_region_shape(self):
+        raise NotImplementedError("region shape / ART (mpeg7Descriptors.py:233-275) is a later "
+                                  "row of the build plan (SURVEY.md 8f); not built yet")
+
+
+EHD_QUANT = [
+    [0.010867, 0.057915, 0.099526, 0.144849, 0.195573, 0.260504, 0.358031, 0.530128],
+    [0.012266, 0.069934, 0.125879, 0.182307, 0.243396, 0.314563, 0.411728, 0.564319],
+    [0.004193, 0.025852, 0.046860, 0.068519, 0.093286, 0.123490, 0.161505, 0.228960],
+    [0.004174, 0.025924, 0.046232, 0.067163, 0.089655, 0.115391, 0.151904, 0.217745],
+    [0.006778, 0.051667, 0.108650, 0.166257, 0.224226, 0.285691, 0.356375, 0.450972]]
+
+
+def ehd_quantise(counts, nblk):
+    """80 three-bit values: nearest reconstruction level of count / blocks-in-sub-image."""
+    out = []
+    for b in range(80):
+        n = int(nblk[b // 5])
+        v = int(counts[b]) / float(n) if n else 0.0
+        tab = EHD_QUANT[b % 5]
+        j = 0
+        while j < 7 and v >= (tab[j] + tab[j + 1]) / 2.0:
+            j += 1
+        out.append(j)
+    return out
+
+
+CSD_AMP_THRESH = [0.000000001, 0.037, 0.08, 0.195, 0.32]
+CSD_AMP_LEVELS = [1, 25, 20, 35, 35, 140]
+
+
+def csd_quantise(hist, nwin):
+    """Non-uniform 8-bit amplitude quantisation of hist / n_windows."""
+    out = [0] * len(hist)
+    if nwin == 0:
+        return out
+    edges = [0.0] + CSD_AMP_THRESH + [1.0]
+    for i, h in enumerate(hist):
+        v = int(h) / float(nwin)
+        base = 0
+        val = 255
+        for r in range(6):
+            lo, hi = edges[r], edges[r + 1]
+            if v < hi or r == 5:
+                if r == 0:
+                    val = 0
+                else:
+                    val = base + int((v - lo) / (hi - lo) * CSD_AMP_LEVELS[r])
+                    val = min(val, base + CSD_AMP_LEVELS[r] - 1)
+                break
+            base += CSD_AMP_LEVELS[r]
+        out[i] = min(val, 255)
+    return out

@@ -88,20 +88,29 @@ int imgan_slic_run(const uint8_t* lab, int B, int H, int W, int S, int nx, int n
  * adjacency) in one pass.  sums: uint64 [B][K][4] = sum c0,c1,c2,count.
  * edges: per image an open-addressed hash set of uint64 keys
  * ((min+1)<<32 | (max+1)), 0 = empty, capacity `edge_cap` (power of two);
- * must be zero-filled by the caller.  Labels >= K are ignored for sums. */
+ * must be zero-filled by the caller (as must sums).  overflow: int32 [B], zero-filled by
+ * the caller, set to 1 if an image's edge set did not fit.  edges may be NULL (sums only).
+ * Labels >= K are ignored for sums. */
 int imgan_rag_accumulate(const uint8_t* img, const int32_t* labels, int B, int H, int W, int K,
-                         uint64_t* sums, uint64_t* edges, int64_t edge_cap,
+                         uint64_t* sums, uint64_t* edges, int64_t edge_cap, int32_t* overflow,
                          imgan_stream_t stream);
 
-/* rag_segmentation.py:77-184 on the host: edge weights from the floor means,
- * stable sort, Kruskal, leave-one-out mean + c*sigma cut, Kruskal again,
- * 1-based ids in surviving-set order.  All pointers are HOST pointers.
- * means: int32 [K][3]; edges_uv: int32 [E][2] (u < v, any order);
- * lut_out: int32 [K] new id per vertex; mst_out: int32 [<=K][2] kept edges,
- * mst_w2_out their squared weights; n_mst_out / n_sets_out counts. */
-int imgan_rag_merge_host(const int32_t* means, int K, const int32_t* edges_uv, int64_t E,
-                         double c_factor, int32_t* lut_out, int32_t* mst_out,
-                         int64_t* mst_w2_out, int32_t* n_mst_out, int32_t* n_sets_out);
+/* rag_segmentation.py:77-184 on the host: edge weights, stable sort, Kruskal,
+ * leave-one-out mean + c*sigma cut, Kruskal again, 1-based ids in surviving-set order.
+ * All pointers are HOST pointers.  Two modes:
+ *   means != NULL (int32 [K][3] floor means), weights == NULL: weights are the euclidean
+ *     distances of the means (find_edges, :77-87); edges_uv in any order, duplicates allowed,
+ *     taken in canonical order (u < v, lexicographic).
+ *   weights != NULL (double [E]), means == NULL: weights as given; edges_uv must already be
+ *     in the caller's discovery order (__convert2arrays, :90-100) without duplicates.
+ * Vertices are 0..K-1 in list order.  lut_out: int32 [K] new id per vertex; mst_out: int32
+ * [<=K][2] kept edges, mst_w_out their weights; members_out: int32 [K] the vertices set by
+ * set in the reference's surviving-list order, set_offsets_out: int32 [n_sets+1].
+ * mst_out, mst_w_out, members_out, set_offsets_out may be NULL. */
+int imgan_rag_merge_host(const int32_t* means, const double* weights, int K,
+                         const int32_t* edges_uv, int64_t E, double c_factor, int32_t* lut_out,
+                         int32_t* mst_out, double* mst_w_out, int32_t* n_mst_out,
+                         int32_t* members_out, int32_t* set_offsets_out, int32_t* n_sets_out);
 
 /* rag_segmentation.py:175-182: out[p] = lut[labels[p]] (labels[p] < 0 or >= K -> 0).
  * lut: int32 [B][K] device. */
@@ -126,16 +135,20 @@ int imgan_cc_label(const int32_t* values, int32_t* roots, int B, int H, int W,
  * assign: uint8 [B][H][W] cluster index per pixel (0xFF outside any segment).
  * state: per-segment loop state, imgan_dcd_state_bytes() bytes, zero-filled
  * before the first round.  One call = one Lloyd round (:86-107) for every
- * segment that has not met the stop rule yet.  active_out (device int32[1],
- * may be NULL) receives the number of segments still running. */
+ * segment that has not met the stop rule yet; first_round != 0 also marks the
+ * pixels outside every segment in `assign`.  active_out (device int32[1], may be
+ * NULL) receives the number of segments still running.  k <= 16. */
 size_t imgan_dcd_state_bytes(int B, int nseg, int k);
 int imgan_dcd_kmeans_round(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
                            int nseg, int k, float* centres, uint8_t* assign, void* state,
-                           int32_t* active_out, imgan_stream_t stream);
+                           int first_round, int32_t* active_out, imgan_stream_t stream);
+/* Per-segment loop state: rounds_out / done_out int32 [B][nseg] (device). */
+int imgan_dcd_rounds(const void* state, int B, int nseg, int k, int32_t* rounds_out,
+                     int32_t* done_out, imgan_stream_t stream);
 
 /* mpeg7Descriptors.py:110-129: per (segment, colour) integer statistics.
  * stats: uint64 [B][nseg][k][8] = count, sum c0..c2, sum of squares c0..c2,
- * size of the largest 8-connected component.  scratch: int32 [B][H][W] x 2. */
+ * size of the largest 8-connected component.  scratch: int32 [B][H][W] x 3. */
 int imgan_dcd_stats(const uint8_t* lab, const int32_t* labels, const uint8_t* assign, int B, int H,
                     int W, int nseg, int k, uint64_t* stats, int32_t* scratch,
                     imgan_stream_t stream);

@@ -13,6 +13,8 @@ All decisions are taken in exact integer arithmetic (stated per function) so
 CPU and GPU cannot disagree through floating-point rounding; the only double
 arithmetic (CLD colour transform and DCT) uses a fixed operation order.
 """
+import math
+
 import numpy as np
 
 from .color import bgr2gray_u8
@@ -29,9 +31,9 @@ def dct_table():
     """c[i][j] = s_i * cos(pi/8 * i * (j + 0.5)), s_0 = sqrt(1/8), s_i = 1/2."""
     c = np.zeros((8, 8), dtype=np.float64)
     for i in range(8):
-        s = np.sqrt(0.125) if i == 0 else 0.5
+        s = math.sqrt(0.125) if i == 0 else 0.5
         for j in range(8):
-            c[i, j] = s * np.cos((np.pi / 8.0) * i * (j + 0.5))
+            c[i, j] = s * math.cos((math.pi / 8.0) * i * (j + 0.5))     # libm, as the C side
     return c
 
 

@@ -1,0 +1,166 @@
+"""GPU parity: connected components, dominant colour, CLD / EHD / CSD vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import voronoi_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.mark.parametrize("shape,nval", [((37, 53), 3), ((128, 200), 5), ((1, 9), 2), ((300, 300), 2)])
+def test_cc_label_matches_scipy(shape, nval):
+    torch = _torch()
+    from scipy import ndimage
+    from imgan import ops
+    rng = np.random.RandomState(3)
+    vals = rng.randint(-1, nval, shape).astype(np.int32)
+    roots = ops.cc_label(torch.from_numpy(vals).cuda())[0].cpu().numpy()
+    assert ((roots < 0) == (vals < 0)).all()
+    flat = np.arange(vals.size).reshape(shape)
+    for v in range(nval):
+        lab, n = ndimage.label(vals == v, structure=np.ones((3, 3)))
+        if n == 0:
+            continue
+        mins = ndimage.minimum(flat, lab, index=np.arange(1, n + 1))   # smallest raster index
+        want = np.asarray(mins)[lab[vals == v] - 1]
+        assert np.array_equal(roots[vals == v], want)
+
+
+def test_cc_spiral_long_chain():
+    """One long snake component: stresses the union-find path lengths."""
+    torch = _torch()
+    from imgan import ops
+    H, W = 65, 129
+    vals = np.full((H, W), -1, dtype=np.int32)
+    for y in range(0, H, 2):
+        vals[y, :] = 0
+        if y + 1 < H:
+            vals[y + 1, W - 1 if (y // 2) % 2 == 0 else 0] = 0
+    roots = ops.cc_label(torch.from_numpy(vals).cuda())[0].cpu().numpy()
+    assert (roots[vals == 0] == 0).all()
+
+
+def _merged_clusters(img, K):
+    from oracle.rag_ref import RAGOracle
+    rag = RAGOracle(img, slic_clust_num=K)
+    cl = rag.run_slic()
+    col = rag.slic_mean_lab(cl, nchange=True)
+    ng = rag.neighbours_regions(cl)
+    return rag.concat_similar_regs(rag.find_edges(ng, col), cl, c_factor=0.65)[0]
+
+
+@pytest.mark.parametrize("H,W,K,k", [(120, 160, 60, 8), (213, 320, 200, 8), (90, 110, 30, 3)])
+def test_dominant_colour_matches_oracle(H, W, K, k):
+    torch = _torch()
+    from mpeg7Descriptors import MPEG7Descriptors
+    from oracle.dcd_ref import DCDOracle
+    img = voronoi_image(H, W, 12, seed=21 + H, noise=14.0)
+    clusters = _merged_clusters(img, K)
+    rng = np.random.RandomState(9)
+    init = {}
+    for seg in np.unique(clusters):
+        n = int((clusters == seg).sum())
+        if n < k:
+            pytest.skip("segment smaller than k")
+        init[int(seg)] = sorted(rng.choice(n, k, replace=False).tolist())
+    mp = MPEG7Descriptors(clusters, img)
+    got = mp.mpeg7_dominant_colours(k, init=init)
+    ora = DCDOracle(clusters, img)
+    want = ora.mpeg7_dominant_colours(k, lambda seg, n, kk: init[seg])
+    assert got.keys() == want.keys()
+    for seg in want:
+        assert mp.dcd_rounds[seg] == ora.rounds[seg], seg            # same stop round
+        for j in range(k):
+            gm, gv, gp, gc = got[seg][j]
+            wm, wv, wp, wc = want[seg][j]
+            # float descriptors: 1e-4 relative (north_star); integers behind them are exact
+            assert np.allclose(gm, wm, rtol=1e-4, atol=0), (seg, j, gm, wm)
+            assert gp == wp and gc == wc, (seg, j)
+            if np.isnan(wv).any():
+                assert np.isnan(gv).all()
+            else:
+                assert np.allclose(gv, wv, rtol=1e-4, atol=1e-9), (seg, j, gv, wv)
+
+
+def test_dominant_colour_single_segment_api():
+    torch = _torch()
+    from mpeg7Descriptors import MPEG7Descriptors
+    from oracle.dcd_ref import dominant_colour
+    from oracle.color import bgr2lab_u8
+    img = voronoi_image(60, 80, 5, seed=4, noise=20.0)
+    clusters = np.zeros((60, 80))
+    clusters[:, 40:] = 1
+    mp = MPEG7Descriptors(clusters, img, seed=123)
+    idx = (clusters == 1)
+    seg_idxs = np.transpose(np.nonzero(idx))
+    pts = bgr2lab_u8(img)[idx]
+    init = [5, 100, 700, 1500]
+    got = mp.dominant_colour(4, pts, seg_idxs, init=init)
+    want, _ = dominant_colour(pts, seg_idxs, init, clusters.shape)
+    for j in range(4):
+        assert np.allclose(got[j][0], want[j][0], rtol=1e-4)
+        assert got[j][2] == want[j][2] and got[j][3] == want[j][3]
+    with pytest.raises(ValueError):                                  # N < k (:79)
+        mp.dominant_colour(8, pts[:3], seg_idxs[:3])
+
+
+SHAPES = [(213, 320), (64, 96), (101, 157), (480, 640), (17, 23), (7, 5)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_cld_ehd_csd_match_oracle(shape):
+    torch = _torch()
+    from imgan import ops
+    from oracle import mpeg7_std as M
+    H, W = shape
+    imgs = np.stack([voronoi_image(H, W, 10, seed=s, noise=10.0) for s in (1, 2, 3)])
+    dev = torch.from_numpy(imgs).cuda()
+    plan = ops.DescriptorPlan(3, H, W)
+    cld = plan.colour_layout(dev).cpu().numpy()
+    ehd = plan.edge_histogram(dev).cpu().numpy()
+    csd = plan.colour_structure(dev).cpu().numpy()
+    for b in range(3):
+        sums, cnt = M.cld_block_sums(imgs[b])
+        assert np.array_equal(cld[b], M.cld_from_sums(sums, cnt))
+        counts, nblk = M.edge_histogram_counts(imgs[b])
+        assert np.array_equal(ehd[b, :80], counts) and np.array_equal(ehd[b, 80:], nblk)
+        hist, nwin = M.colour_structure_counts(imgs[b])
+        assert np.array_equal(csd[b, :256], hist) and csd[b, 256] == nwin
+
+
+@pytest.mark.parametrize("nbins", [32, 64, 128, 256])
+def test_hmmd_quantiser_exhaustive_slice(nbins):
+    torch = _torch()
+    from imgan import ops
+    from oracle.mpeg7_std import hmmd_quantise
+    # every (g, r) for 32 blue levels incl. extremes: 2^21 colours
+    b = np.array(sorted(set(list(range(0, 256, 9)) + [1, 2, 127, 128, 254, 255])), dtype=np.uint8)
+    g, r = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8))
+    img = np.stack([np.broadcast_to(b[:, None, None], (len(b), 256, 256)),
+                    np.broadcast_to(g, (len(b), 256, 256)),
+                    np.broadcast_to(r, (len(b), 256, 256))], axis=-1).copy()
+    got = ops.hmmd_quantise(torch.from_numpy(img).cuda(), nbins).cpu().numpy()
+    want = hmmd_quantise(img, nbins)
+    assert np.array_equal(got, want)
+    assert want.max() == nbins - 1 and want.min() == 0
+
+
+def test_descriptor_methods_on_class():
+    torch = _torch()
+    from mpeg7Descriptors import MPEG7Descriptors
+    from oracle import mpeg7_std as M
+    img = voronoi_image(213, 320, 10, seed=8)
+    mp = MPEG7Descriptors(np.zeros((213, 320)), img)
+    assert mp.mpeg7_colour_layout() == M.colour_layout(img).tolist()
+    c, n = M.edge_histogram_counts(img)
+    assert mp.mpeg7_edge_histogram() == M.ehd_quantise(c, n).tolist()
+    h, nw = M.colour_structure_counts(img)
+    assert mp.mpeg7_colour_structure() == M.csd_quantise(h, nw).tolist()
+    with pytest.raises(NotImplementedError):
+        mp.mpeg7_region_shape()

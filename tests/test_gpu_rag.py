@@ -1,0 +1,122 @@
+"""GPU parity: median blur, RAG (means, adjacency, merge, relabel) vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import voronoi_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.mark.parametrize("shape", [(40, 56), (213, 320), (9, 5), (67, 131)])
+def test_median7_matches_oracle(shape):
+    torch = _torch()
+    from imgan import ops
+    from oracle.color import median_blur
+    rng = np.random.RandomState(11)
+    img = rng.randint(0, 256, shape + (3,)).astype(np.uint8)
+    got = ops.median7(torch.from_numpy(img).cuda()).cpu().numpy()
+    assert np.array_equal(got, median_blur(img, 7))
+    const = np.full(shape + (3,), 93, dtype=np.uint8)          # KAT: median of a constant
+    assert np.array_equal(ops.median7(torch.from_numpy(const).cuda()).cpu().numpy(), const)
+
+
+@pytest.mark.parametrize("H,W,K,c", [(213, 320, 200, 0.65), (120, 160, 60, 0.65),
+                                     (101, 157, 40, 2.0), (96, 128, 300, 0.6)])
+def test_rag_pipeline_matches_oracle(H, W, K, c):
+    """The caller's sequence (optigen_utils.py:41-47) step by step against the oracle."""
+    torch = _torch()
+    from rag_segmentation import RAGSegmentation
+    from oracle.rag_ref import RAGOracle
+    img = voronoi_image(H, W, max(K // 4, 6), seed=77 + H)
+    rag = RAGSegmentation(img.copy(), slic_clust_num=K, slic_cw=15, median_blur=7)
+    ora = RAGOracle(img.copy(), slic_clust_num=K, slic_cw=15, median_blur_k=7)
+    assert np.array_equal(rag.image, ora.image)
+    assert np.array_equal(rag.image_lab, ora.image_lab)
+
+    t_clusters = rag.run_slic()
+    o_clusters = ora.run_slic()
+    assert np.array_equal(t_clusters, o_clusters)
+
+    col = rag.slic_mean_lab(t_clusters)
+    ocol = ora.slic_mean_lab(o_clusters)
+    assert sorted(col.keys()) == list(range(K))
+    for k in range(K):
+        assert np.array_equal(np.asarray(col[k], dtype=np.int64), np.asarray(ocol[k], dtype=np.int64))
+    assert np.array_equal(rag.image_lab, ora.image_lab)         # painted means (:45-46)
+
+    cn = rag.neighbours_regions(t_clusters)
+    ocn = ora.neighbours_regions(o_clusters)
+    assert cn == ocn
+    for k, s in cn.items():                                      # symmetric, -1 never appears
+        assert -1.0 not in s
+        for v in s:
+            assert float(k) in cn[int(v)]
+
+    ed = rag.find_edges(cn, col)
+    oed = ora.find_edges(ocn, ocol)
+    assert ed.keys() == oed.keys()
+    for k in ed:
+        assert [(a, float(b)) for a, b in ed[k]] == [(a, float(b)) for a, b in oed[k]]
+
+    new, emst, wmst, vmst = rag.concat_similar_regs(ed, t_clusters, c_factor=c)
+    onew, oemst, owmst, ovmst = ora.concat_similar_regs(oed, o_clusters, c_factor=c)
+    assert new.dtype == np.float64
+    assert np.array_equal(new, onew)                             # ids included (canonical order)
+    assert emst == oemst and vmst == ovmst
+    assert np.allclose(wmst, owmst, rtol=0, atol=0)
+    assert (new[-1, :] == 0).all() and (new[:, -1] == 0).all()   # -1 border becomes id 0 (:176)
+
+    rgb = rag.slic_mean_rgb(new)
+    orgb = ora.slic_mean_rgb(onew)
+    for k in range(K):
+        assert np.array_equal(np.asarray(rgb[k], dtype=np.int64), np.asarray(orgb[k], dtype=np.int64))
+    assert np.array_equal(rag.image_mean, ora.image_mean)
+
+
+def test_rag_batch_merge_means_mode():
+    """Device sums + hash-set adjacency + C++ merge (means mode) + LUT relabel, batch of 2."""
+    torch = _torch()
+    from imgan import ops
+    from oracle.rag_ref import RAGOracle
+    K = 80
+    imgs = [voronoi_image(150, 200, 30, seed=s) for s in (5, 6)]
+    oras = [RAGOracle(im, slic_clust_num=K) for im in imgs]
+    labels = np.stack([o.run_slic() for o in oras]).astype(np.int32)
+    blur = np.stack([o.image for o in oras])
+    lab = np.stack([o.image_lab for o in oras])
+    dlab = torch.from_numpy(lab).cuda()
+    dlabels = torch.from_numpy(labels).cuda()
+    sums, edges = ops.rag_accumulate(dlab, dlabels, K)
+    s = sums.cpu().numpy()
+    luts = []
+    for b, o in enumerate(oras):
+        col = o.slic_mean_lab(labels[b].astype(np.float64), nchange=True)
+        means = np.where(s[b, :, 3:4] > 0, s[b, :, :3] // np.maximum(s[b, :, 3:4], 1), 0)
+        assert np.array_equal(means, np.array([col[c] for c in range(K)], dtype=np.int64))
+        ng = o.neighbours_regions(labels[b].astype(np.float64))
+        ref_edges = sorted((u, int(v)) for u in ng for v in ng[u] if u < v)
+        assert [tuple(e) for e in edges[b].tolist()] == ref_edges
+        res = ops.rag_merge_host(K, edges[b], 0.65, means=means)
+        onew, oe, ow, ov = o.concat_similar_regs(o.find_edges(ng, col), labels[b].astype(np.float64), 0.65)
+        assert res["mst"].tolist() == oe and res["sets"] == ov
+        luts.append(res["lut"])
+        out = ops.relabel(dlabels[b:b + 1], torch.from_numpy(res["lut"]).cuda())[0].cpu().numpy()
+        assert np.array_equal(out.astype(np.float64), onew)
+    both = ops.relabel(dlabels, torch.from_numpy(np.stack(luts)).cuda()).cpu().numpy()
+    assert both.shape == labels.shape
+
+
+def test_adjacency_checkerboard_kat():
+    """2x2 checkerboard of labels: diagonal neighbours count (8-connectivity)."""
+    torch = _torch()
+    from imgan import ops
+    lab = np.array([[0, 1, -1], [2, 3, -1], [-1, -1, -1]], dtype=np.int32)
+    img = torch.zeros((1, 3, 3, 3), dtype=torch.uint8, device="cuda")
+    _, edges = ops.rag_accumulate(img, torch.from_numpy(lab).cuda().unsqueeze(0), 4)
+    assert [tuple(e) for e in edges[0].tolist()] == [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
