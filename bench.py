@@ -54,35 +54,6 @@ def synth_batch(B, H, W, K, seed, device):
     return out
 
 
-class Pipeline(object):
-    """Lab -> SLIC -> descriptors for a resident batch; all compute in libimgan_hip.so."""
-
-    def __init__(self, B, H, W, K, cw, num_iter):
-        from imgan import ops
-        self.ops = ops
-        self.B, self.H, self.W, self.K, self.cw, self.num_iter = B, H, W, K, cw, num_iter
-        self.plan = ops.SlicPlan(B, H, W, K)
-        self.lab = torch.empty((B, H, W, 3), dtype=torch.uint8, device="cuda")
-        self.assign_events = []
-        self.desc = ops.DescriptorPlan(B, H, W, self.plan.n) if hasattr(ops, "DescriptorPlan") else None
-
-    def step(self, bgr, timed=False):
-        ops, plan = self.ops, self.plan
-        ops.bgr2lab(bgr, out=self.lab)
-        plan.init(self.lab)
-        for _ in range(1, self.num_iter):
-            if timed:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                plan.round(self.lab, self.cw, events=(e0, e1))
-                self.assign_events.append((e0, e1))
-            else:
-                plan.round(self.lab, self.cw)
-        if self.desc is not None:
-            return self.desc.run(bgr, self.lab, plan.labels)
-        return plan.centres.view(self.B, -1).float()
-
-
 def cpu_baseline(H, W, K, cw):
     """The oracle (numpy restatement with the reference's cost structure, slic.py:88-126:
     per-centre window ops + per-label full-image scans) on a bounded sample."""
@@ -129,23 +100,25 @@ def main():
     B, H, W, K = args.batch, args.height, args.width, args.clusters
     cw, num_iter = 15, 10
     bgr = synth_batch(B, H, W, K, 1234 + rank * B, "cuda")
-    pipe = Pipeline(B, H, W, K, cw, num_iter)
+    from imgan.pipeline import FullPipeline
+    from imgan.shard import gather_descriptors
+    pipe = FullPipeline(B, H, W, K, colour_weight=cw, num_iter=num_iter, dominant=8)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    gathered = None
+    index = None
     for _ in range(args.warmup):
-        d = pipe.step(bgr)
+        pipe.step(bgr)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        d = pipe.step(bgr, timed=True)
-        if world > 1:
-            gathered = [torch.empty_like(d) for _ in range(world)]
-            dist.all_gather(gathered, d)
+        image_rows, region_rows = pipe.step(bgr, timed=True)
+        # one collective per step: the descriptor rows of every rank -> replicated index
+        index = (gather_descriptors(image_rows, n_total=B * world),
+                 gather_descriptors(region_rows, n_total=B * world))
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -169,8 +142,9 @@ def main():
             "dtype": "u8/int32 (integer keys; f32 Lloyd, f64 ties)", "data": "synthetic",
             "config": {"workload": "configs[1]: %d x %dx%d BGR per GPU, K=%d (n=%d, S=%d), "
                                    "num_iter=%d, cw=%d, %s" %
-                                   (B, W, H, K, pipe.plan.n, pipe.plan.S, num_iter, cw,
-                                    "Lab+SLIC+CLD+EHD+CSD+DCD" if pipe.desc else "Lab+SLIC only"),
+                                   (B, W, H, K, pipe.n, pipe.slic.S, num_iter, cw,
+                                    "Lab + SLIC + CLD + EHD + CSD(256) + DCD(k=8 per superpixel, "
+                                    "%d Lloyd rounds)" % pipe.dcd_rounds_run),
                        "global_batch": B * world, "parallelism": "batch-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "slic_assign_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -263,6 +263,84 @@ __global__ __launch_bounds__(256) void dcd_largest_kernel(const int32_t* __restr
     }
 }
 
+// ---- deterministic stand-in for random.sample(segment, k) (:79) for device-resident batches:
+// pixel p competes for slot j = h(p) % k of its segment; the slot goes to the smallest
+// (h(p), p).  k distinct pixels per segment, reproducible, no host round trip.
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void dcd_init_pick_kernel(const int32_t* __restrict__ labels,
+                                                            long long npix, int nseg, int k,
+                                                            uint32_t seed,
+                                                            unsigned long long* __restrict__ slots) {
+    const int b = blockIdx.y;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * 256) {
+        int s = labels[(size_t)b * npix + p];
+        if (s < 0 || s >= nseg) continue;
+        uint32_t h = mix32((uint32_t)p * 0x9e3779b1u + seed);
+        unsigned long long key = ((unsigned long long)h << 32) | (unsigned long long)(uint32_t)p;
+        unsigned long long* slot = slots + ((size_t)b * nseg + s) * k + (h % (uint32_t)k);
+        // the slot only ever decreases: a stale read just costs an extra atomic
+        if (key < __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMin(slot, key);
+    }
+}
+
+__global__ void dcd_init_fetch_kernel(const uint8_t* __restrict__ lab, long long npix, int nsegs,
+                                      int nseg, int k, const unsigned long long* __restrict__ slots,
+                                      float* __restrict__ centres) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nsegs) return;
+    int b = t / nseg;
+    const unsigned long long* sl = slots + (size_t)t * k;
+    unsigned long long fallback = ~0ull;
+    for (int j = 0; j < k; ++j) fallback = sl[j] < fallback ? sl[j] : fallback;
+    for (int j = 0; j < k; ++j) {
+        unsigned long long key = sl[j] != ~0ull ? sl[j] : fallback;   // empty slot: tiny segment
+        float* c = centres + ((size_t)t * k + j) * 3;
+        if (key == ~0ull) {
+            c[0] = c[1] = c[2] = 0.f;                                  // segment without pixels
+        } else {
+            const uint8_t* q = lab + ((size_t)b * npix + (uint32_t)key) * 3;
+            c[0] = (float)q[0];
+            c[1] = (float)q[1];
+            c[2] = (float)q[2];
+        }
+    }
+}
+
+// stats + centres -> [mean(3), var(3), percentage, coherence] as float32 (mpeg7Descriptors.py:114-129)
+__global__ void dcd_features_kernel(const unsigned long long* __restrict__ stats,
+                                    const float* __restrict__ centres, int nsegs, int k,
+                                    float* __restrict__ out) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nsegs) return;
+    const unsigned long long* st = stats + (size_t)t * k * 8;
+    unsigned long long total = 0;
+    for (int j = 0; j < k; ++j) total += st[8 * j];
+    for (int j = 0; j < k; ++j) {
+        const unsigned long long* a = st + 8 * j;
+        float* o = out + ((size_t)t * k + j) * 8;
+        const float* c = centres + ((size_t)t * k + j) * 3;
+        o[0] = c[0];
+        o[1] = c[1];
+        o[2] = c[2];
+        double n = (double)a[0];
+        for (int ch = 0; ch < 3; ++ch) {
+            double sx = (double)a[1 + ch], sxx = (double)a[4 + ch];
+            o[3 + ch] = a[0] ? (float)((n * sxx - sx * sx) / (n * n)) : __builtin_nanf("");
+        }
+        o[6] = total ? (float)(n / (double)total) : 0.f;
+        o[7] = a[0] ? (float)((double)a[7] / n) : 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t imgan_dcd_state_bytes(int B, int nseg, int k) {
@@ -336,4 +414,34 @@ extern "C" int imgan_dcd_stats(const uint8_t* lab, const int32_t* labels, const 
                        (const int32_t*)roots, (const int32_t*)sizes, npix, nseg * k,
                        (unsigned long long*)stats);
     return imgan::check_launch("imgan_dcd_stats");
+}
+
+extern "C" int imgan_dcd_init_hash(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
+                                   int nseg, int k, uint32_t seed, float* centres, uint64_t* slots,
+                                   imgan_stream_t stream) {
+    IMGAN_REQUIRE(lab && labels && centres && slots, "imgan_dcd_init_hash: null pointer");
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535, "imgan_dcd_init_hash: bad shape");
+    IMGAN_REQUIRE(k >= 1 && k <= KMAX, "imgan_dcd_init_hash: 1 <= k <= 16 dominant colours");
+    IMGAN_REQUIRE((long long)H * W < 0x7fffffffLL, "imgan_dcd_init_hash: image too large");
+    hipStream_t st = (hipStream_t)stream;
+    long long npix = (long long)H * W;
+    IMGAN_HIP(hipMemsetAsync(slots, 0xff, (size_t)B * nseg * k * sizeof(uint64_t), st));
+    dim3 grid((unsigned)std::min<long long>(imgan::cdiv(npix, 256), 8192), (unsigned)B);
+    hipLaunchKernelGGL(dcd_init_pick_kernel, grid, dim3(256), 0, st, labels, npix, nseg, k, seed,
+                       (unsigned long long*)slots);
+    int nsegs = B * nseg;
+    hipLaunchKernelGGL(dcd_init_fetch_kernel, dim3(imgan::cdiv(nsegs, 128)), dim3(128), 0, st, lab,
+                       npix, nsegs, nseg, k, (const unsigned long long*)slots, centres);
+    return imgan::check_launch("imgan_dcd_init_hash");
+}
+
+extern "C" int imgan_dcd_features(const uint64_t* stats, const float* centres, int B, int nseg,
+                                  int k, float* features, imgan_stream_t stream) {
+    IMGAN_REQUIRE(stats && centres && features, "imgan_dcd_features: null pointer");
+    IMGAN_REQUIRE(B >= 1 && nseg >= 1 && k >= 1 && k <= KMAX, "imgan_dcd_features: bad shape");
+    int nsegs = B * nseg;
+    hipLaunchKernelGGL(dcd_features_kernel, dim3(imgan::cdiv(nsegs, 128)), dim3(128), 0,
+                       (hipStream_t)stream, (const unsigned long long*)stats, centres, nsegs, k,
+                       features);
+    return imgan::check_launch("dcd_features_kernel");
 }

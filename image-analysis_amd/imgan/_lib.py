@@ -47,6 +47,9 @@ SIGNATURES = {
     "imgan_dcd_kmeans_round": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "imgan_dcd_rounds": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "imgan_dcd_init_hash": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    ctypes.c_uint32, c_void_p, c_void_p, c_void_p]),
+    "imgan_dcd_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "imgan_dcd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p]),
     "imgan_cld": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

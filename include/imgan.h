@@ -146,6 +146,19 @@ int imgan_dcd_kmeans_round(const uint8_t* lab, const int32_t* labels, int B, int
 int imgan_dcd_rounds(const void* state, int B, int nseg, int k, int32_t* rounds_out,
                      int32_t* done_out, imgan_stream_t stream);
 
+/* Device-side, reproducible stand-in for the reference's unseeded random.sample(segment, k)
+ * (mpeg7Descriptors.py:79): pixel p competes for slot hash(p, seed) % k of its segment and the
+ * smallest (hash, p) wins, giving k distinct pixels per segment.  centres: float32
+ * [B][nseg][k][3] out; slots: uint64 [B][nseg][k] scratch (winning hash<<32 | pixel). */
+int imgan_dcd_init_hash(const uint8_t* lab, const int32_t* labels, int B, int H, int W, int nseg,
+                        int k, uint32_t seed, float* centres, uint64_t* slots,
+                        imgan_stream_t stream);
+
+/* mpeg7Descriptors.py:114-129 from the integer statistics: features float32 [B][nseg][k][8] =
+ * mean(3), population variance(3), percentage, spatial coherence. */
+int imgan_dcd_features(const uint64_t* stats, const float* centres, int B, int nseg, int k,
+                       float* features, imgan_stream_t stream);
+
 /* mpeg7Descriptors.py:110-129: per (segment, colour) integer statistics.
  * stats: uint64 [B][nseg][k][8] = count, sum c0..c2, sum of squares c0..c2,
  * size of the largest 8-connected component.  scratch: int32 [B][H][W] x 3. */

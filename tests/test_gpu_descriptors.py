@@ -164,3 +164,69 @@ def test_descriptor_methods_on_class():
     assert mp.mpeg7_colour_structure() == M.csd_quantise(h, nw).tolist()
     with pytest.raises(NotImplementedError):
         mp.mpeg7_region_shape()
+
+
+def _mix32(h):
+    h = h.astype(np.uint64)
+    m = np.uint64(0xffffffff)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85ebca6b)) & m
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xc2b2ae35)) & m
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def test_full_pipeline_batch_matches_oracle():
+    """configs[1] in miniature: Lab -> SLIC -> per-superpixel dominant colours (device-side
+    hash init) + CLD/EHD/CSD for a batch of 2, each stage against the oracle."""
+    torch = _torch()
+    from imgan.pipeline import FullPipeline
+    from oracle.color import bgr2lab_u8
+    from oracle.slic_ref import SLICOracle
+    from oracle.dcd_ref import dominant_colour
+    from oracle import mpeg7_std as M
+    H, W, K, k, seed = 120, 160, 30, 4, 777
+    imgs = np.stack([voronoi_image(H, W, 10, seed=s, noise=12.0) for s in (31, 32)])
+    pipe = FullPipeline(2, H, W, K, colour_weight=15, num_iter=10, dominant=k, dcd_seed=seed,
+                        dcd_check_every=1)
+    rows, feats = pipe.step(torch.from_numpy(imgs).cuda())
+    rows = rows.cpu().numpy()
+    feats = feats.cpu().numpy().reshape(2, pipe.n, k, 8)
+    labels = pipe.slic.labels.cpu().numpy()
+    for b in range(2):
+        lab = bgr2lab_u8(imgs[b])
+        o = SLICOracle(lab=lab, num_clusters=K, colour_weight=15, num_iter=10)
+        assert np.array_equal(o.run().astype(np.int32), labels[b])
+        cld = M.colour_layout(imgs[b])
+        counts, nblk = M.edge_histogram_counts(imgs[b])
+        hist, nwin = M.colour_structure_counts(imgs[b])
+        want = np.concatenate([cld, counts, nblk, hist, [nwin]])
+        assert np.array_equal(rows[b], want)
+        # device init rule restated: slot j of a segment <- smallest (mix32(p*c + seed), p), h % k == j
+        p = np.arange(H * W, dtype=np.uint64)
+        h = _mix32((p * np.uint64(0x9e3779b1) + np.uint64(seed)) & np.uint64(0xffffffff))
+        flat = labels[b].ravel()
+        for s in range(pipe.n):
+            idx = np.nonzero(flat == s)[0]
+            if len(idx) == 0:
+                continue
+            hs = h[idx]
+            init = []
+            for j in range(k):
+                cand = np.nonzero(hs % np.uint64(k) == j)[0]
+                assert len(cand), "test segments are large enough for every slot"
+                best = cand[np.lexsort((idx[cand], hs[cand]))[0]]
+                init.append(int(best))
+            pts = lab.reshape(-1, 3)[idx]
+            seg_idxs = np.stack(np.divmod(idx, W), axis=1)
+            want_f, _ = dominant_colour(pts, seg_idxs, init, (H, W))
+            for j in range(k):
+                wm, wv, wp, wc = want_f[j]
+                g = feats[b, s, j]
+                assert np.allclose(g[0:3], wm, rtol=1e-4, atol=0), (b, s, j)
+                if np.isnan(wv).any():
+                    assert np.isnan(g[3:6]).all()
+                else:
+                    assert np.allclose(g[3:6], wv, rtol=1e-4, atol=1e-6), (b, s, j)
+                assert np.isclose(g[6], wp, rtol=1e-6) and np.isclose(g[7], wc, rtol=1e-6)
