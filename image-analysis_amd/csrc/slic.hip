@@ -23,18 +23,27 @@
 #include "common.h"
 #include "../../include/imgan.h"
 #include <math.h>
+#include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
 constexpr int TW = 64;      // tile width  (16 lanes x 4 pixels)
 constexpr int TH = 16;      // tile height (4 waves x 4 rows)
-constexpr int MAXC = 40;    // centres per tile handled by the LDS fast path
+constexpr int NSUBMAX = 4; // bands of 16 rows per tile (pixels of all bands prefetched)
+constexpr int MAXC = 48;    // most centres per tile the LDS fast path can be sized for
 constexpr int NFIELD = 6;   // sum L, a, b, x, y, count
+constexpr int TILE_REC = 1 + MAXC;   // int4 records per tile: header {m} + sorted candidates
 
 struct Layout {
     int ncx, ncy, ncell;
-    size_t off_count, off_start, off_fill, off_items, off_cand, off_sums, total;
+    int nsub, ntx, nty;          // assignment tiles: 64 x (16*nsub) pixels
+    size_t off_count, off_start, off_fill, off_scand, off_cand, off_sums, off_tiles, total;
 };
+
+// taller tiles amortise the per-tile prologue / flush; small steps keep them short so that the
+// number of centres reaching a tile stays below MAXC
+int choose_nsub(int S) { return S >= 48 ? 4 : (S >= 28 ? 2 : 1); }
 
 Layout make_layout(int B, int H, int W, int S, int n) {
     Layout L;
@@ -50,9 +59,15 @@ Layout make_layout(int B, int H, int W, int S, int n) {
     L.off_count = take((size_t)B * L.ncell * 4);
     L.off_fill = take((size_t)B * L.ncell * 4);
     L.off_start = take((size_t)B * (L.ncell + 1) * 4);
-    L.off_items = take((size_t)B * n * 4);
+    L.off_scand = take((size_t)B * n * 16);
     L.off_cand = take((size_t)B * n * 16);
     L.off_sums = take((size_t)B * n * NFIELD * 8);
+    L.nsub = choose_nsub(S);
+    L.ntx = (W - 1 + TW - 1) / TW;
+    L.nty = (H - 1 + TH * L.nsub - 1) / (TH * L.nsub);
+    if (L.ntx < 1) L.ntx = 1;
+    if (L.nty < 1) L.nty = 1;
+    L.off_tiles = take((size_t)B * L.ntx * L.nty * TILE_REC * 16);
     L.total = o;
     return L;
 }
@@ -61,10 +76,12 @@ struct Ws {
     int* count;
     int* fill;
     int* start;
-    int* items;
+    int4* scand;            // cell-sorted copy of cand with .w = centre index
     int4* cand;             // cx, cy, packed Lab (L | a<<8 | b<<16), cell
     unsigned long long* sums;
+    int4* tiles;            // [B][nty][ntx][TILE_REC]: {m,..}, then {cx, cy, lab, idx} by idx
     int ncx, ncy, ncell;
+    int nsub, ntx, nty;
 };
 
 Ws bind(void* ws, const Layout& L) {
@@ -73,12 +90,16 @@ Ws bind(void* ws, const Layout& L) {
     w.count = (int*)(p + L.off_count);
     w.fill = (int*)(p + L.off_fill);
     w.start = (int*)(p + L.off_start);
-    w.items = (int*)(p + L.off_items);
+    w.scand = (int4*)(p + L.off_scand);
     w.cand = (int4*)(p + L.off_cand);
     w.sums = (unsigned long long*)(p + L.off_sums);
     w.ncx = L.ncx;
     w.ncy = L.ncy;
     w.ncell = L.ncell;
+    w.tiles = (int4*)(p + L.off_tiles);
+    w.nsub = L.nsub;
+    w.ntx = L.ntx;
+    w.nty = L.nty;
     return w;
 }
 
@@ -166,10 +187,64 @@ __global__ void slic_fill_kernel(Ws w, int B, int n) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * n) return;
     int b = t / n, c = t - b * n;
-    int cell = w.cand[t].w;
-    int pos = w.start[(size_t)b * (w.ncell + 1) + cell] +
-              atomicAdd(&w.fill[(size_t)b * w.ncell + cell], 1);
-    w.items[(size_t)b * n + pos] = c;
+    int4 q = w.cand[t];
+    int pos = w.start[(size_t)b * (w.ncell + 1) + q.w] +
+              atomicAdd(&w.fill[(size_t)b * w.ncell + q.w], 1);
+    q.w = c;
+    w.scand[(size_t)b * n + pos] = q;
+}
+
+// ------------------------------------------------------------------ per-tile candidate lists
+// One wave per assignment tile: collects the centres whose window can reach the tile from the
+// cell lists, sorts them by centre index and writes a fixed-size record.  Doing this in its
+// own (tiny) launch takes two dependent memory round trips out of every assignment workgroup.
+__global__ __launch_bounds__(256) void slic_tiles_kernel(Ws w, int B, int H, int W, int S, int n) {
+    __shared__ int4 u_c[4][MAXC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ntiles = w.ntx * w.nty;
+    const long long t = (long long)blockIdx.x * 4 + wv;
+    const bool live = t < (long long)B * ntiles;
+    int m = 0;
+    int b = 0, x0 = 0, y0 = 0;
+    if (live) {
+        b = (int)(t / ntiles);
+        const int ti = (int)(t - (long long)b * ntiles);
+        const int ty = ti / w.ntx, tx = ti - ty * w.ntx;
+        x0 = tx * TW;
+        y0 = ty * (TH * w.nsub);
+        const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + TH * w.nsub - 1, H - 2);
+        // centres that can cover a pixel of the tile: cx in [x0-S+1, x1+S], cy likewise
+        const int cxl = max(x0 - S + 1, 0) / S, cxh = min((x1 + S) / S, w.ncx - 1);
+        const int cyl = max(y0 - S + 1, 0) / S, cyh = min((y1 + S) / S, w.ncy - 1);
+        const int4* scand = w.scand + (size_t)b * n;
+        const int* start = w.start + (size_t)b * (w.ncell + 1);
+        for (int cyc = cyl; cyc <= cyh; ++cyc) {
+            const int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
+            for (int i0 = beg; i0 < end; i0 += 64) {
+                const int i = i0 + lane;
+                bool hit = false;
+                int4 q = make_int4(0, 0, 0, 0);
+                if (i < end) {
+                    q = scand[i];
+                    hit = q.x >= x0 - S + 1 && q.x <= x1 + S && q.y >= y0 - S + 1 && q.y <= y1 + S;
+                }
+                const unsigned long long vote = __ballot(hit);
+                const int slot = m + __popcll(vote & ((1ull << lane) - 1ull));
+                if (hit && slot < MAXC) u_c[wv][slot] = q;
+                m += __popcll(vote);
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    int4* rec = w.tiles + (size_t)t * TILE_REC;
+    if (lane == 0) rec[0] = make_int4(m, x0, y0, 0);
+    if (lane < m && m <= MAXC) {
+        const int4 me = u_c[wv][lane];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += (u_c[wv][j].w < me.w);
+        rec[1 + rank] = me;
+    }
 }
 
 // ------------------------------------------------------------------ assignment
@@ -178,7 +253,7 @@ struct __attribute__((packed, aligned(4))) Dword3 {
 };
 
 struct AssignParams {
-    int B, H, W, S, n;
+    int B, H, W, S, n, nsub, maxc, dbg;
     unsigned S2, cw2;         // integer key weights (modes 0, 1)
     double Sd, cw;            // literal float64 evaluation (mode 2 and exact-key ties)
 };
@@ -235,27 +310,30 @@ __device__ __forceinline__ void flush_pixel_global(unsigned long long* sums, int
     atomicAdd(&s[5], 1ull);
 }
 
-// MODE 0: u32 key with the dot4 expansion (fast path); 1: u64; 2: double.
+// MODE 0: u32 key with the dot4 expansion (fast path); 1: u64; 2: literal float64.
+//
+// One workgroup = a 64 x (16*nsub) pixel tile: the candidate list is gathered once and reused
+// for nsub bands of 16 rows (wave w takes rows 4w..4w+3 of each band, 16 lanes x 4 pixels per
+// row), so the latency of the gather (two dependent loads) and of the flush is amortised.
 template <int MODE, bool ALIGNED>
 __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restrict__ lab,
                                                           int32_t* __restrict__ labels, Ws w,
                                                           AssignParams P) {
-    __shared__ int s_m;                       // candidates reaching this tile
-    __shared__ int u_idx[MAXC], u_cx[MAXC], u_cy[MAXC], u_lab[MAXC];      // unsorted
-    __shared__ int s_idx[MAXC], s_cx[MAXC], s_cy[MAXC];                    // sorted, tile relative
-    __shared__ uint32_t s_lab[MAXC], s_A[MAXC];
-    __shared__ int s_Bx[MAXC], s_By[MAXC];
-    __shared__ __attribute__((aligned(16))) uint32_t acc[MAXC * 3 * 64];   // [slot][word][lane] lane-private partial sums
-    __shared__ uint32_t red[MAXC * 6];
+    // dynamic LDS, sized by the host for the number of centres a tile is expected to see
+    // (P.maxc): fewer bytes per workgroup = more workgroups per CU to hide the prologue.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int maxc = P.maxc;
+    int4* s_c0 = reinterpret_cast<int4*>(smem);          // by centre index: {cx', cy', lab, A}
+    int4* s_c1 = s_c0 + maxc;                            //                  {Bx, By, idx, 0}
+    uint32_t* acc = reinterpret_cast<uint32_t*>(s_c1 + maxc);   // [slot][word][lane] partial sums
 
     const int b = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int H = P.H, W = P.W, S = P.S, n = P.n;
-    const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + TH - 1, H - 2);
+    const int H = P.H, W = P.W, S = P.S, n = P.n, nsub = P.nsub;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * (TH * nsub);
+    const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + TH * nsub - 1, H - 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    const int4* cand = w.cand + (size_t)b * n;
-    const int* items = w.items + (size_t)b * n;
+    const int4* scand = w.scand + (size_t)b * n;
     const int* start = w.start + (size_t)b * (w.ncell + 1);
     unsigned long long* sums = w.sums + (size_t)b * n * NFIELD;
 
@@ -263,259 +341,293 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
     const int cxl = max(x0 - S + 1, 0) / S, cxh = min((x1 + S) / S, w.ncx - 1);
     const int cyl = max(y0 - S + 1, 0) / S, cyh = min((y1 + S) / S, w.ncy - 1);
 
-    if (tid == 0) s_m = 0;
-    __syncthreads();
-    for (int cyc = cyl; cyc <= cyh; ++cyc) {
-        int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
-        for (int i = beg + tid; i < end; i += 256) {
-            int c = items[i];
-            int4 q = cand[c];
-            if (q.x >= x0 - S + 1 && q.x <= x1 + S && q.y >= y0 - S + 1 && q.y <= y1 + S) {
-                int slot = atomicAdd(&s_m, 1);
-                if (slot < MAXC) {
-                    u_idx[slot] = c;
-                    u_cx[slot] = q.x;
-                    u_cy[slot] = q.y;
-                    u_lab[slot] = q.z;
-                }
+    const int xr = (lane & 15) * 4;                      // tile relative column of pixel 0
+    const int x = x0 + xr;
+    const bool colok = x < W - 1;
+
+    // Every band's pixels are requested up front, before the candidate gather: the kernel is
+    // bound by bytes in flight, so each wave keeps nsub x 768 B outstanding instead of one
+    // row group at a time (measured: one group in flight ~1.3 TB/s for the bare skeleton).
+    auto unpack = [&](const Dword3& v, uint32_t* px) {
+        px[0] = v.a & 0xffffffu;
+        px[1] = __builtin_amdgcn_perm(v.b, v.a, 0x0c050403u);
+        px[2] = __builtin_amdgcn_perm(v.c, v.b, 0x0c040302u);
+        px[3] = v.c >> 8;
+    };
+    auto load_px = [&](int yy, uint32_t* px) {           // generic (unaligned rows) loader
+        px[0] = px[1] = px[2] = px[3] = 0;
+        if (yy < H - 1 && colok) {
+            const uint8_t* src = lab + (((size_t)b * H + yy) * W + x) * 3;
+            if (ALIGNED) {
+                unpack(*reinterpret_cast<const Dword3*>(src), px);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (x + j < W) {
+                        const uint8_t* q = src + 3 * j;
+                        px[j] = q[0] | (q[1] << 8) | (q[2] << 16);
+                    }
             }
         }
-    }
-    __syncthreads();
-    const int m = s_m;
-
-    // this lane's 4 pixels
-    const int xr = (lane & 15) * 4, yr = wave * 4 + (lane >> 4);   // tile relative
-    const int x = x0 + xr, y = y0 + yr;
-    const bool rowok = (y < H - 1);
-    uint32_t px[4] = {0, 0, 0, 0};
-    if (rowok && x < W - 1) {
-        const uint8_t* src = lab + (((size_t)b * H + y) * W + x) * 3;
-        if (ALIGNED) {
-            Dword3 v = *reinterpret_cast<const Dword3*>(src);
-            px[0] = v.a & 0xffffffu;
-            px[1] = __builtin_amdgcn_perm(v.b, v.a, 0x0c050403u);
-            px[2] = __builtin_amdgcn_perm(v.c, v.b, 0x0c040302u);
-            px[3] = v.c >> 8;
-        } else {
+    };
+    Dword3 raw[NSUBMAX];
+    if (ALIGNED) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (x + j < W) {
-                    const uint8_t* s = src + 3 * j;
-                    px[j] = s[0] | (s[1] << 8) | (s[2] << 16);
-                }
+        for (int sub = 0; sub < NSUBMAX; ++sub) {
+            raw[sub].a = raw[sub].b = raw[sub].c = 0;
+            const int yy = y0 + sub * TH + wave * 4 + (lane >> 4);
+            if (sub < nsub && yy < H - 1 && colok)
+                raw[sub] = *reinterpret_cast<const Dword3*>(lab + (((size_t)b * H + yy) * W + x) * 3);
         }
     }
-    bool valid[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) valid[j] = rowok && (x + j < W - 1);
 
-    const size_t lbase = ((size_t)b * H + y) * W + x;
+    // the tile's sorted candidate record (slic_tiles_kernel): one round trip, every lane of
+    // the first wave fetches one entry whether it is used or not
+    const int4* rec = w.tiles + ((size_t)b * w.ntx * w.nty + (size_t)blockIdx.y * w.ntx + blockIdx.x) * TILE_REC;
+    const int m = rec[0].x;
+    int4 mine = make_int4(0, 0, 0, 0);
+    if (tid < MAXC) mine = rec[1 + tid];
+    for (int i = tid; i < maxc * 3 * 16; i += 256)
+        reinterpret_cast<uint4*>(acc)[i] = make_uint4(0, 0, 0, 0);
 
-    if (m > MAXC) {
+    if (m > maxc) {
         // ---- slow path: too many centres around this tile (degenerate inputs).  Every lane
         // walks the cell lists itself and flushes with global atomics.  Exact, just slower.
-        for (int j = 0; j < 4; ++j) {
-            if (!valid[j]) continue;
-            typename KeyT<MODE == 2 ? 2 : 1>::type best = 0;
-            int bi = -1;
-            for (int cyc = cyl; cyc <= cyh; ++cyc) {
-                int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
-                for (int i = beg; i < end; ++i) {
-                    int c = items[i];
-                    int4 q = cand[c];
-                    if ((unsigned)(x + j - q.x + S) >= (unsigned)(2 * S) ||
-                        (unsigned)(y - q.y + S) >= (unsigned)(2 * S))
-                        continue;
-                    auto k = generic_key<MODE == 2 ? 2 : 1>(px[j], x + j, y, q.z, q.x, q.y, P);
-                    bool take = bi < 0 || k < best;
-                    if (!take && k == best) {
-                        // equal exact keys: the reference compares the rounded float64 values,
-                        // and on equality the lower centre index (earlier in its sweep) stays
-                        double dn = literal_dist(px[j], x + j, y, q.z, q.x, q.y, P.Sd, P.cw);
-                        int4 qb = cand[bi];
-                        double db = literal_dist(px[j], x + j, y, qb.z, qb.x, qb.y, P.Sd, P.cw);
-                        take = dn < db || (dn == db && c < bi);
-                    }
-                    if (take) {
-                        best = k;
-                        bi = c;
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int y = y0 + sub * TH + wave * 4 + (lane >> 4);
+            uint32_t px[4];
+            load_px(y, px);
+            for (int j = 0; j < 4; ++j) {
+                if (!(y < H - 1 && x + j < W - 1)) continue;
+                const size_t li = ((size_t)b * H + y) * W + x + j;
+                typename KeyT<MODE == 2 ? 2 : 1>::type best = 0;
+                int bi = -1;
+                int4 qb = make_int4(0, 0, 0, 0);
+                for (int cyc = cyl; cyc <= cyh; ++cyc) {
+                    int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
+                    for (int i = beg; i < end; ++i) {
+                        int4 q = scand[i];
+                        if ((unsigned)(x + j - q.x + S) >= (unsigned)(2 * S) ||
+                            (unsigned)(y - q.y + S) >= (unsigned)(2 * S))
+                            continue;
+                        auto k = generic_key<MODE == 2 ? 2 : 1>(px[j], x + j, y, q.z, q.x, q.y, P);
+                        bool take = bi < 0 || k < best;
+                        if (!take && k == best) {
+                            // equal exact keys: the reference compares the rounded float64
+                            // values; on equality the lower centre index (earlier) stays
+                            double dn = literal_dist(px[j], x + j, y, q.z, q.x, q.y, P.Sd, P.cw);
+                            double db = literal_dist(px[j], x + j, y, qb.z, qb.x, qb.y, P.Sd, P.cw);
+                            take = dn < db || (dn == db && q.w < bi);
+                        }
+                        if (take) {
+                            best = k;
+                            bi = q.w;
+                            qb = q;
+                        }
                     }
                 }
+                int lbl = bi;
+                if (bi >= 0)
+                    labels[li] = bi;
+                else
+                    lbl = labels[li];
+                if (lbl >= 0) flush_pixel_global(sums, lbl, px[j], x + j, y);
             }
-            int lbl = bi;
-            if (bi >= 0)
-                labels[lbase + j] = bi;
-            else
-                lbl = labels[lbase + j];
-            if (lbl >= 0) flush_pixel_global(sums, lbl, px[j], x + j, y);
         }
         return;
     }
 
-    // ---- sort the candidate list by centre index (rank sort, m <= MAXC) and precompute
+    // ---- candidates into LDS, tile relative, with the per-candidate terms of the key
     if (tid < m) {
-        int me = u_idx[tid], rank = 0;
-        for (int j = 0; j < m; ++j) rank += (u_idx[j] < me);
-        int cxr = u_cx[tid] - x0, cyr = u_cy[tid] - y0;
-        uint32_t cl = (uint32_t)u_lab[tid];
-        s_idx[rank] = me;
-        s_cx[rank] = cxr;
-        s_cy[rank] = cyr;
-        s_lab[rank] = cl;
+        int cxr = mine.x - x0, cyr = mine.y - y0;
+        uint32_t cl = (uint32_t)mine.z;
+        uint32_t A = 0;
+        int Bx = 0, By = 0;
         if (MODE == 0) {
             uint32_t cc = __builtin_amdgcn_udot4(cl, cl, 0u, false);
-            s_A[rank] = P.S2 * cc + P.cw2 * (uint32_t)(cxr * cxr + cyr * cyr);
-            s_Bx[rank] = 2 * (int)P.cw2 * cxr;
-            s_By[rank] = 2 * (int)P.cw2 * cyr;
+            A = P.S2 * cc + P.cw2 * (uint32_t)(cxr * cxr + cyr * cyr);
+            Bx = 2 * (int)P.cw2 * cxr;
+            By = 2 * (int)P.cw2 * cyr;
         }
+        s_c0[tid] = make_int4(cxr, cyr, (int)cl, (int)A);
+        s_c1[tid] = make_int4(Bx, By, mine.w, 0);
     }
-    for (int i = tid; i < m * 3 * 64; i += 256) acc[i] = 0;
     __syncthreads();
 
-    int slot[4] = {-1, -1, -1, -1};
     const unsigned twoS = 2u * S;
-    if (MODE == 0) {
-        uint32_t best[4], T[4];
+    const int S2x2 = 2 * (int)P.S2;
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int yr = sub * TH + wave * 4 + (lane >> 4);       // tile relative row
+        const int y = y0 + yr;
+        const int wy0 = sub * TH + wave * 4;                      // rows wy0..wy0+3 in this wave
+        if (y0 + wy0 >= H - 1) continue;                          // whole wave below the image
+        uint32_t px[4];
+        if (ALIGNED) {
+            Dword3 v = raw[0];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            best[j] = 0xffffffffu;
-            uint32_t pp = __builtin_amdgcn_udot4(px[j], px[j], 0u, false);
-            T[j] = pp * P.S2 + P.cw2 * (uint32_t)((xr + j) * (xr + j) + yr * yr);
+            for (int k = 1; k < NSUBMAX; ++k)
+                if (sub == k) v = raw[k];
+            unpack(v, px);
+        } else {
+            load_px(y, px);
         }
-        const int S2x2 = 2 * (int)P.S2;
-        for (int s = 0; s < m; ++s) {
-            const int cyr = s_cy[s];
-            // wave-level cull: rows of this wave are yr0..yr0+3
-            const int wy0 = wave * 4;
-            if (cyr - S > wy0 + 3 || cyr + S - 1 < wy0) continue;
-            const int cxr = s_cx[s];
-            const uint32_t cl = s_lab[s];
-            const bool iny = (unsigned)(yr - cyr + S) < twoS;
-            const uint32_t R = s_A[s] - (uint32_t)__mul24(s_By[s], yr);
-            const int Bx = s_Bx[s];
+        const bool rowok = (y < H - 1);
+        bool valid[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) valid[j] = rowok && (x + j < W - 1);
+        const size_t lbase = ((size_t)b * H + y) * W + x;
+
+        int slot[4] = {-1, -1, -1, -1};
+        unsigned tied = 0;                  // bit j: the best key of pixel j was met again
+        if (MODE == 0) {
+            // Branch-free inner loop (selects only): per pixel and candidate one dot4, one
+            // 24-bit mad, one add for the key; the window test and the running minimum are
+            // compares + selects.  tc[j] counts how often the current best key was met again.
+            uint32_t best[4], T[4], tc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                uint32_t pc = __builtin_amdgcn_udot4(px[j], cl, 0u, false);
-                uint32_t key = T[j] + R - (uint32_t)__mul24(S2x2, (int)pc) -
-                               (uint32_t)__mul24(Bx, xr + j);
-                bool in = iny && ((unsigned)(xr + j - cxr + S) < twoS);
-                if (in && key <= best[j]) {
-                    bool take = key < best[j];
-                    if (!take && slot[j] >= 0) {
-                        // equal exact keys (rare): the reference compares the float64 values
-                        int sb = slot[j];
-                        take = literal_dist(px[j], xr + j, yr, cl, cxr, cyr, P.Sd, P.cw) <
-                               literal_dist(px[j], xr + j, yr, s_lab[sb], s_cx[sb], s_cy[sb], P.Sd,
-                                            P.cw);
-                    }
-                    if (take) {
+                best[j] = 0xffffffffu;
+                tc[j] = 0;
+                uint32_t pp = __builtin_amdgcn_udot4(px[j], px[j], 0u, false);
+                T[j] = pp * P.S2 + P.cw2 * (uint32_t)((xr + j) * (xr + j) + yr * yr);
+            }
+            const int mm = (P.dbg & 4) ? min(m, 1) : m;
+            for (int s = 0; s < mm; ++s) {
+                const int4 c0 = s_c0[s];
+                if (c0.y - S > wy0 + 3 || c0.y + S - 1 < wy0) continue;     // wave-level cull
+                const int2 bxy = *reinterpret_cast<const int2*>(&s_c1[s]);
+                const bool iny = (unsigned)(yr - c0.y + S) < twoS;
+                const int d0 = xr - c0.x + S;
+                // R + T = key without the colour dot product and the x cross term
+                const uint32_t Q0 = (uint32_t)c0.w - (uint32_t)__mul24(bxy.y, yr) -
+                                    (uint32_t)__mul24(bxy.x, xr);
+                const uint32_t cl = (uint32_t)c0.z;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t pc = __builtin_amdgcn_udot4(px[j], cl, 0u, false);
+                    const uint32_t base = T[j] + (Q0 - (uint32_t)(j * bxy.x));
+                    const uint32_t key = (uint32_t)(__mul24(-S2x2, (int)pc) + (int)base);
+                    const bool in = iny & ((unsigned)(d0 + j) < twoS);
+                    const bool lt = in & (key < best[j]);
+                    const bool eq = in & (key == best[j]);
+                    tc[j] = lt ? 0u : tc[j] + (eq ? 1u : 0u);
+                    best[j] = lt ? key : best[j];
+                    slot[j] = lt ? s : slot[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tied |= (tc[j] != 0u && slot[j] >= 0) ? (1u << j) : 0u;
+        } else {
+            typename KeyT<MODE>::type best[4];
+            for (int s = 0; s < m; ++s) {
+                const int4 c0 = s_c0[s];
+                const bool iny = (unsigned)(yr - c0.y + S) < twoS;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bool in = iny && ((unsigned)(xr + j - c0.x + S) < twoS);
+                    if (!in) continue;
+                    auto key = generic_key<MODE>(px[j], xr + j, yr, (uint32_t)c0.z, c0.x, c0.y, P);
+                    if (slot[j] < 0 || key < best[j]) {
                         best[j] = key;
                         slot[j] = s;
+                        tied &= ~(1u << j);
+                    } else if (MODE == 1 && key == best[j]) {
+                        tied |= 1u << j;
                     }
                 }
             }
         }
-    } else {
-        typename KeyT<MODE>::type best[4];
-        for (int s = 0; s < m; ++s) {
-            const int cyr = s_cy[s], cxr = s_cx[s];
-            const uint32_t cl = s_lab[s];
-            const bool iny = (unsigned)(yr - cyr + S) < twoS;
+        // ---- equal exact keys (rare): the reference compares the rounded float64 distances in
+        // centre order with a strict '<', so replay the candidates that cover the pixel.
+        if (tied) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                bool in = iny && ((unsigned)(xr + j - cxr + S) < twoS);
-                if (!in) continue;
-                auto key = generic_key<MODE>(px[j], xr + j, yr, cl, cxr, cyr, P);
-                bool take = slot[j] < 0 || key < best[j];
-                if (MODE == 1 && !take && key == best[j]) {
-                    int sb = slot[j];
-                    take = literal_dist(px[j], xr + j, yr, cl, cxr, cyr, P.Sd, P.cw) <
-                           literal_dist(px[j], xr + j, yr, s_lab[sb], s_cx[sb], s_cy[sb], P.Sd, P.cw);
+                if (!((tied >> j) & 1u)) continue;
+                const int4 cb = s_c0[slot[j]];
+                const auto kbest = generic_key<1>(px[j], xr + j, yr, (uint32_t)cb.z, cb.x, cb.y, P);
+                double dbest = 0.0;
+                int sb = -1;
+                for (int s = 0; s < m; ++s) {
+                    const int4 c0 = s_c0[s];
+                    if ((unsigned)(yr - c0.y + S) >= twoS || (unsigned)(xr + j - c0.x + S) >= twoS)
+                        continue;
+                    if (generic_key<1>(px[j], xr + j, yr, (uint32_t)c0.z, c0.x, c0.y, P) != kbest)
+                        continue;
+                    double d = literal_dist(px[j], xr + j, yr, (uint32_t)c0.z, c0.x, c0.y, P.Sd, P.cw);
+                    if (sb < 0 || d < dbest) {
+                        dbest = d;
+                        sb = s;
+                    }
                 }
-                if (take) {
-                    best[j] = key;
-                    slot[j] = s;
-                }
+                slot[j] = sb;
             }
         }
-    }
 
-    // ---- labels out + accumulate
-    bool all4 = true;
+        // ---- labels out + accumulate
+        bool all4 = true;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) all4 = all4 && valid[j] && slot[j] >= 0;
-    if (ALIGNED && all4) {
-        int4 o = make_int4(s_idx[slot[0]], s_idx[slot[1]], s_idx[slot[2]], s_idx[slot[3]]);
-        *reinterpret_cast<int4*>(labels + lbase) = o;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (valid[j] && slot[j] >= 0) labels[lbase + j] = s_idx[slot[j]];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (!valid[j]) continue;
-        if (slot[j] >= 0) {
-            uint32_t p = px[j];
-            uint32_t* a = acc + slot[j] * 192 + lane;
-            atomicAdd(a, (p & 0xffu) | ((p & 0xff00u) << 8));
-            atomicAdd(a + 64, ((p >> 16) & 0xffu) | 0x10000u);
-            atomicAdd(a + 128, (uint32_t)(xr + j) | ((uint32_t)yr << 16));
+        for (int j = 0; j < 4; ++j) all4 = all4 && valid[j] && slot[j] >= 0;
+        if (P.dbg & 2) {
+        } else if (ALIGNED && all4) {
+            int4 o = make_int4(s_c1[slot[0]].z, s_c1[slot[1]].z, s_c1[slot[2]].z, s_c1[slot[3]].z);
+            *reinterpret_cast<int4*>(labels + lbase) = o;
         } else {
-            int old = labels[lbase + j];      // not covered this round: keeps its label
-            if (old >= 0) flush_pixel_global(sums, old, px[j], x + j, y);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (valid[j] && slot[j] >= 0) labels[lbase + j] = s_c1[slot[j]].z;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!valid[j] || (P.dbg & 1)) continue;
+            if (slot[j] >= 0) {
+                uint32_t p = px[j];
+                uint32_t* a = acc + slot[j] * 192 + lane;
+                atomicAdd(a, (p & 0xffu) | ((p & 0xff00u) << 8));
+                atomicAdd(a + 64, ((p >> 16) & 0xffu) | 0x10000u);
+                atomicAdd(a + 128, (uint32_t)(xr + j) | ((uint32_t)yr << 16));
+            } else {
+                int old = labels[lbase + j];      // not covered this round: keeps its label
+                if (old >= 0) flush_pixel_global(sums, old, px[j], x + j, y);
+            }
         }
     }
     __syncthreads();
 
-    // ---- reduce the 64 lane-private copies: 4 threads per (slot, word) row, 16 copies each.
-    // Packed halves cannot overflow: a copy sums <= 16 pixels, 16 copies <= 65280 per half.
-    for (int row0 = 0; row0 < m * 3; row0 += 64) {
-        int row = row0 + (tid >> 2), q = tid & 3;
+    // ---- reduce the 64 lane-private copies and flush: 16 lanes per slot = 4 lanes for each of
+    // its 3 packed rows (L|a, b|count, x'|y'), 16 copies per lane.  A copy holds at most
+    // 4 waves x 4 bands x 4 pixels = 64 pixels, so its 16-bit halves cannot overflow
+    // (64 * 255 < 65536); the halves are widened before they are summed.
+    for (int s0 = 0; s0 < m; s0 += 16) {
+        const int s = s0 + (tid >> 4), r = (tid >> 2) & 3, q = tid & 3;
+        const bool live = s < m && r < 3;
         uint32_t lo = 0, hi = 0;
-        if (row < m * 3) {
-            const uint4* src = reinterpret_cast<const uint4*>(acc + row * 64 + q * 16);
-            uint32_t sum = 0;
+        if (live) {
+            const uint4* src = reinterpret_cast<const uint4*>(acc + (s * 3 + r) * 64 + q * 16);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 uint4 v = src[k];
-                sum += v.x + v.y + v.z + v.w;
+                lo += (v.x & 0xffffu) + (v.y & 0xffffu) + (v.z & 0xffffu) + (v.w & 0xffffu);
+                hi += (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
             }
-            lo = sum & 0xffffu;
-            hi = sum >> 16;
         }
         lo += __shfl_xor(lo, 1);
         hi += __shfl_xor(hi, 1);
         lo += __shfl_xor(lo, 2);
         hi += __shfl_xor(hi, 2);
-        if (row < m * 3 && q == 0) {
-            red[row * 2] = lo;
-            red[row * 2 + 1] = hi;
+        const uint32_t cnt = __shfl(hi, (lane & 48) + 4);      // row 1 of this slot: b | count
+        if (live && q == 0 && cnt) {
+            unsigned long long* dst = sums + (size_t)s_c1[s].z * NFIELD;
+            if (r == 0) {
+                atomicAdd(&dst[0], (unsigned long long)lo);
+                atomicAdd(&dst[1], (unsigned long long)hi);
+            } else if (r == 1) {
+                atomicAdd(&dst[2], (unsigned long long)lo);
+                atomicAdd(&dst[5], (unsigned long long)cnt);
+            } else {
+                atomicAdd(&dst[3], (unsigned long long)lo + (unsigned long long)cnt * x0);
+                atomicAdd(&dst[4], (unsigned long long)hi + (unsigned long long)cnt * y0);
+            }
         }
-    }
-    __syncthreads();
-    // red[slot*6 + {0:L, 1:a, 2:b, 3:count, 4:x', 5:y'}]
-    for (int i = tid; i < m * 6; i += 256) {
-        int s = i / 6, f = i - s * 6;
-        uint32_t cnt = red[s * 6 + 3];
-        if (cnt == 0) continue;
-        unsigned long long v;
-        int field;
-        if (f < 3) {
-            v = red[i];
-            field = f;
-        } else if (f == 3) {
-            v = cnt;
-            field = 5;
-        } else if (f == 4) {
-            v = (unsigned long long)red[i] + (unsigned long long)cnt * x0;
-            field = 3;
-        } else {
-            v = (unsigned long long)red[i] + (unsigned long long)cnt * y0;
-            field = 4;
-        }
-        if (v) atomicAdd(&sums[(size_t)s_idx[s] * NFIELD + field], v);
     }
 }
 
@@ -534,8 +646,8 @@ int key_mode(int S, double cw) {
     double r = rint(cw);
     if (r != cw || cw < 1.0 || cw > 4096.0) return 2;
     double cw2 = cw * cw, S2 = (double)S * S;
-    bool fits32 = S2 * (195075.0 + 2.0 * cw2) < 4294967295.0 && 2.0 * cw2 * (TW + S) < 8388608.0 &&
-                  2.0 * S2 < 8388608.0;
+    bool fits32 = S2 * (195075.0 + 2.0 * cw2) < 4294967295.0 &&
+                  2.0 * cw2 * (4 * TH + TW + S) < 8388608.0 && 2.0 * S2 < 8388608.0;
     return fits32 ? 0 : 1;
 }
 
@@ -603,6 +715,9 @@ extern "C" int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres
                        centres, w, B, H, W, S, n);
     hipLaunchKernelGGL(slic_scan_kernel, dim3(B), dim3(1024), 0, st, w);
     hipLaunchKernelGGL(slic_fill_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, w, B, n);
+    long long ntiles = (long long)B * L.ntx * L.nty;
+    hipLaunchKernelGGL(slic_tiles_kernel, dim3((unsigned)imgan::cdiv(ntiles, 4)), dim3(256), 0, st,
+                       w, B, H, W, S, n);
     return imgan::check_launch("slic_bin_centres");
 }
 
@@ -624,9 +739,17 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
     P.S2 = (unsigned)(S * S);
     P.cw2 = mode == 2 ? 0u : (unsigned)(colour_weight * colour_weight);
     bool aligned = (W % 4 == 0) && (((uintptr_t)lab & 3) == 0) && (((uintptr_t)labels & 15) == 0);
-    dim3 grid((unsigned)imgan::cdiv(W - 1, TW), (unsigned)imgan::cdiv(H - 1, TH), (unsigned)B);
+    P.nsub = L.nsub;
+    // LDS is sized for about twice the expected number of centres around a tile
+    double m_est = (double)(TW + 2 * S) * (TH * L.nsub + 2 * S) / ((double)S * S);
+    P.maxc = std::min(MAXC, std::max(16, ((int)(2.0 * m_est) + 4 + 7) / 8 * 8));
+    size_t lds_bytes = (size_t)P.maxc * (2 * sizeof(int4) + 3 * 64 * sizeof(uint32_t));
+    P.dbg = 0;
+    if (const char* e = getenv("IMGAN_SLIC_DEBUG")) P.dbg = atoi(e);
+    dim3 grid((unsigned)L.ntx, (unsigned)L.nty, (unsigned)B);
+    IMGAN_REQUIRE(grid.y <= 65535, "imgan_slic_assign_accumulate: image too tall");
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(M, A) hipLaunchKernelGGL((slic_assign_kernel<M, A>), grid, dim3(256), 0, st, lab, labels, w, P)
+#define LAUNCH(M, A) hipLaunchKernelGGL((slic_assign_kernel<M, A>), grid, dim3(256), lds_bytes, st, lab, labels, w, P)
     if (mode == 0) { if (aligned) LAUNCH(0, true); else LAUNCH(0, false); }
     else if (mode == 1) { if (aligned) LAUNCH(1, true); else LAUNCH(1, false); }
     else { if (aligned) LAUNCH(2, true); else LAUNCH(2, false); }

@@ -1,0 +1,26 @@
+"""Runs one stage of the path on a synthetic batch (for rocprofv3 counter passes).
+usage: python3 tools/prof_stage.py {slic|dcd|desc|all} [B]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "image-analysis_amd"))
+sys.path.insert(0, ROOT)
+import torch
+from bench import synth_batch
+from imgan.pipeline import FullPipeline
+
+stage = sys.argv[1] if len(sys.argv) > 1 else "slic"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+bgr = synth_batch(B, 1080, 1920, 400, 1234, "cuda")
+pipe = FullPipeline(B, 1080, 1920, 400)
+for rep in range(2):
+    pipe.run_slic(bgr)
+    if stage in ("dcd", "all"):
+        pipe.run_dcd()
+    if stage in ("desc", "all"):
+        pipe.desc.colour_layout(bgr)
+        pipe.desc.edge_histogram(bgr)
+        pipe.desc.colour_structure(bgr)
+torch.cuda.synchronize()
+print("done", stage, B)
