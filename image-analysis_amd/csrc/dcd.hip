@@ -17,35 +17,11 @@
 #include "common.h"
 #include "../../include/imgan.h"
 #include "cc_device.h"
+#include "dcd_common.h"
+
+using namespace imgan_dcd;
 
 namespace {
-
-constexpr int KMAX = 16;          // dominant colours per segment supported by the kernels
-constexpr int HCAP = 512;         // LDS hash capacity (entries)
-
-struct SegState {
-    double old_sum;
-    int done;
-    int rounds;
-};
-
-struct DcdLayout {
-    size_t off_seg, off_oldcen, off_acc, total;
-};
-
-DcdLayout dcd_layout(int B, int nseg, int k) {
-    DcdLayout L;
-    size_t nsegs = (size_t)B * nseg;
-    size_t o = 0;
-    L.off_seg = o;
-    o = imgan::align_up(o + nsegs * sizeof(SegState), 256);
-    L.off_oldcen = o;
-    o = imgan::align_up(o + nsegs * k * 3 * sizeof(float), 256);
-    L.off_acc = o;
-    o = imgan::align_up(o + nsegs * k * 4 * sizeof(unsigned long long), 256);
-    L.total = o;
-    return L;
-}
 
 template <int NF>
 struct BlockHash {
@@ -201,7 +177,7 @@ __global__ __launch_bounds__(256) void dcd_values_kernel(
     const uint8_t* __restrict__ lab, const int32_t* __restrict__ labels,
     const uint8_t* __restrict__ assign, long long npix, int nseg, int k,
     int32_t* __restrict__ values, int32_t* __restrict__ sizes,
-    unsigned long long* __restrict__ stats) {
+    unsigned long long* __restrict__ stats, const SegState* __restrict__ seg) {
     __shared__ BlockHash<7> tab;
     tab.init();
     __syncthreads();
@@ -217,6 +193,7 @@ __global__ __launch_bounds__(256) void dcd_values_kernel(
         values[gp] = key;
         sizes[gp] = 0;
         if (key < 0) continue;
+        if (seg && seg[(size_t)b * nseg + s].handled) continue;   // sums already final
         const uint8_t* q = lab + gp * 3;
         uint32_t u0 = q[0], u1 = q[1], u2 = q[2];
         uint32_t v[7] = {1u, u0, u1, u2, u0 * u0, u1 * u1, u2 * u2};
@@ -235,6 +212,19 @@ __global__ __launch_bounds__(256) void dcd_values_kernel(
         for (int f = 0; f < 7; ++f)
             if (tab.vals[i * 7 + f]) atomicAdd(&a[f], (unsigned long long)tab.vals[i * 7 + f]);
     }
+}
+
+__global__ void dcd_zero_stats_kernel(unsigned long long* __restrict__ stats, int nsegs, int k,
+                                      const SegState* __restrict__ seg) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nsegs * k) return;
+    int s = t / k;
+    unsigned long long* a = stats + (size_t)t * 8;
+    if (seg && seg[s].handled) {
+        a[7] = 0ull;                      // only the largest-component slot is recomputed
+        return;
+    }
+    for (int f = 0; f < 8; ++f) a[f] = 0ull;
 }
 
 __global__ __launch_bounds__(256) void dcd_sizes_kernel(const int32_t* __restrict__ roots,
@@ -266,24 +256,17 @@ __global__ __launch_bounds__(256) void dcd_largest_kernel(const int32_t* __restr
 // ---- deterministic stand-in for random.sample(segment, k) (:79) for device-resident batches:
 // pixel p competes for slot j = h(p) % k of its segment; the slot goes to the smallest
 // (h(p), p).  k distinct pixels per segment, reproducible, no host round trip.
-__device__ __forceinline__ uint32_t mix32(uint32_t h) {
-    h ^= h >> 16;
-    h *= 0x85ebca6bu;
-    h ^= h >> 13;
-    h *= 0xc2b2ae35u;
-    h ^= h >> 16;
-    return h;
-}
-
 __global__ __launch_bounds__(256) void dcd_init_pick_kernel(const int32_t* __restrict__ labels,
                                                             long long npix, int nseg, int k,
                                                             uint32_t seed,
-                                                            unsigned long long* __restrict__ slots) {
+                                                            unsigned long long* __restrict__ slots,
+                                                            const SegState* __restrict__ seg) {
     const int b = blockIdx.y;
     for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix;
          p += (long long)gridDim.x * 256) {
         int s = labels[(size_t)b * npix + p];
         if (s < 0 || s >= nseg) continue;
+        if (seg && seg[(size_t)b * nseg + s].handled) continue;
         uint32_t h = mix32((uint32_t)p * 0x9e3779b1u + seed);
         unsigned long long key = ((unsigned long long)h << 32) | (unsigned long long)(uint32_t)p;
         unsigned long long* slot = slots + ((size_t)b * nseg + s) * k + (h % (uint32_t)k);
@@ -294,9 +277,11 @@ __global__ __launch_bounds__(256) void dcd_init_pick_kernel(const int32_t* __res
 
 __global__ void dcd_init_fetch_kernel(const uint8_t* __restrict__ lab, long long npix, int nsegs,
                                       int nseg, int k, const unsigned long long* __restrict__ slots,
-                                      float* __restrict__ centres) {
+                                      float* __restrict__ centres,
+                                      const SegState* __restrict__ seg) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nsegs) return;
+    if (seg && seg[t].handled) return;
     int b = t / nseg;
     const unsigned long long* sl = slots + (size_t)t * k;
     unsigned long long fallback = ~0ull;
@@ -391,7 +376,7 @@ extern "C" int imgan_dcd_rounds(const void* state, int B, int nseg, int k, int32
 
 extern "C" int imgan_dcd_stats(const uint8_t* lab, const int32_t* labels, const uint8_t* assign,
                                int B, int H, int W, int nseg, int k, uint64_t* stats,
-                               int32_t* scratch, imgan_stream_t stream) {
+                               int32_t* scratch, const void* state, imgan_stream_t stream) {
     IMGAN_REQUIRE(lab && labels && assign && stats && scratch, "imgan_dcd_stats: null pointer");
     IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535, "imgan_dcd_stats: bad shape");
     IMGAN_REQUIRE(k >= 1 && k <= KMAX, "imgan_dcd_stats: 1 <= k <= 16 dominant colours");
@@ -403,10 +388,14 @@ extern "C" int imgan_dcd_stats(const uint8_t* lab, const int32_t* labels, const 
     int32_t* roots = scratch + plane;
     int32_t* sizes = scratch + 2 * plane;
     hipStream_t st = (hipStream_t)stream;
-    IMGAN_HIP(hipMemsetAsync(stats, 0, (size_t)B * nseg * k * 8 * sizeof(uint64_t), st));
+    const SegState* seg = state ? (const SegState*)((const char*)state + dcd_layout(B, nseg, k).off_seg)
+                                : nullptr;
+    int nsk = B * nseg * k;
+    hipLaunchKernelGGL(dcd_zero_stats_kernel, dim3(imgan::cdiv(nsk, 256)), dim3(256), 0, st,
+                       (unsigned long long*)stats, B * nseg, k, seg);
     dim3 grid8((unsigned)imgan::cdiv(npix, 256 * 8), (unsigned)B);
     hipLaunchKernelGGL(dcd_values_kernel, grid8, dim3(256), 0, st, lab, labels, assign, npix, nseg,
-                       k, values, sizes, (unsigned long long*)stats);
+                       k, values, sizes, (unsigned long long*)stats, seg);
     if (int rc = imgan_cc_label(values, roots, B, H, W, stream)) return rc;
     dim3 grid((unsigned)std::min<long long>(imgan::cdiv(npix, 256), 16384), (unsigned)B);
     hipLaunchKernelGGL(dcd_sizes_kernel, grid, dim3(256), 0, st, (const int32_t*)roots, sizes, npix);
@@ -418,7 +407,7 @@ extern "C" int imgan_dcd_stats(const uint8_t* lab, const int32_t* labels, const 
 
 extern "C" int imgan_dcd_init_hash(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
                                    int nseg, int k, uint32_t seed, float* centres, uint64_t* slots,
-                                   imgan_stream_t stream) {
+                                   const void* state, imgan_stream_t stream) {
     IMGAN_REQUIRE(lab && labels && centres && slots, "imgan_dcd_init_hash: null pointer");
     IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535, "imgan_dcd_init_hash: bad shape");
     IMGAN_REQUIRE(k >= 1 && k <= KMAX, "imgan_dcd_init_hash: 1 <= k <= 16 dominant colours");
@@ -427,11 +416,13 @@ extern "C" int imgan_dcd_init_hash(const uint8_t* lab, const int32_t* labels, in
     long long npix = (long long)H * W;
     IMGAN_HIP(hipMemsetAsync(slots, 0xff, (size_t)B * nseg * k * sizeof(uint64_t), st));
     dim3 grid((unsigned)std::min<long long>(imgan::cdiv(npix, 256), 8192), (unsigned)B);
+    const SegState* seg = state ? (const SegState*)((const char*)state + dcd_layout(B, nseg, k).off_seg)
+                                : nullptr;
     hipLaunchKernelGGL(dcd_init_pick_kernel, grid, dim3(256), 0, st, labels, npix, nseg, k, seed,
-                       (unsigned long long*)slots);
+                       (unsigned long long*)slots, seg);
     int nsegs = B * nseg;
     hipLaunchKernelGGL(dcd_init_fetch_kernel, dim3(imgan::cdiv(nsegs, 128)), dim3(128), 0, st, lab,
-                       npix, nsegs, nseg, k, (const unsigned long long*)slots, centres);
+                       npix, nsegs, nseg, k, (const unsigned long long*)slots, centres, seg);
     return imgan::check_launch("imgan_dcd_init_hash");
 }
 

@@ -48,10 +48,14 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "imgan_dcd_rounds": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_dcd_init_hash": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                    ctypes.c_uint32, c_void_p, c_void_p, c_void_p]),
+                                    ctypes.c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "imgan_dcd_bbox_bytes": (c_size_t, [c_int, c_int]),
+    "imgan_dcd_segments": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   ctypes.c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_void_p]),
     "imgan_dcd_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "imgan_dcd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                c_void_p, c_void_p, c_void_p]),
+                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "imgan_cld": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_cld_scratch_bytes": (c_size_t, [c_int]),
     "imgan_ehd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

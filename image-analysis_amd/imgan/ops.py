@@ -272,7 +272,10 @@ def cc_label(values):
 
 
 class DcdPlan(object):
-    """Dominant colours of every segment of a label map (mpeg7Descriptors.py:76-130)."""
+    """Dominant colours of every segment of a label map (mpeg7Descriptors.py:76-130).
+
+    Segments that fit on chip are finished by the LDS-resident kernel in one launch; larger
+    ones (merged regions) continue through the streaming rounds.  Both give the same numbers."""
 
     def __init__(self, B, H, W, nseg, k):
         _require_gpu()
@@ -282,13 +285,21 @@ class DcdPlan(object):
                                  dtype=torch.uint8, device=dev)
         self.assign = torch.empty((self.B, self.H, self.W), dtype=torch.uint8, device=dev)
         self.active = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.n_big = torch.zeros(1, dtype=torch.int32, device=dev)
         self.stats = torch.empty((self.B, self.nseg, self.k, 8), dtype=torch.int64, device=dev)
+        self.bbox = torch.empty(lib.imgan_dcd_bbox_bytes(self.B, self.nseg), dtype=torch.uint8,
+                                device=dev)
+        self.slots = None
         self.scratch = None
-        self.rounds_run = 0
+        self.rounds_run = 0          # streaming rounds issued for the large segments
+        self.big_segments = 0
 
-    def kmeans(self, lab, labels, centres, max_rounds=1000, check_every=1):
-        """Runs Lloyd rounds until every segment met the reference's stop rule.
-        centres: float32 [B,nseg,k,3], updated in place."""
+    def kmeans(self, lab, labels, centres, seed=None, max_rounds=1000, check_every=1,
+               streaming_only=False):
+        """Runs every segment's Lloyd loop to the reference's stop rule.
+        centres: float32 [B,nseg,k,3], updated in place; with seed is not None they are
+        sampled on the device (hash rule of imgan_dcd_init_hash), otherwise they must hold
+        the initial centres."""
         lab = as_batch(_dev(lab, torch.uint8, "lab"))
         if labels.dim() == 2:
             labels = labels.unsqueeze(0)
@@ -296,12 +307,34 @@ class DcdPlan(object):
         _dev(centres, torch.float32, "centres")
         if tuple(centres.shape) != (self.B, self.nseg, self.k, 3):
             raise ValueError("centres must be [B,nseg,k,3]")
-        self.state.zero_()
+        use_hash = seed is not None
+        cseed = ctypes.c_uint32(int(seed) & 0xffffffff if use_hash else 0)
+        shape = (self.B, self.H, self.W, self.nseg, self.k)
+        state_for_skip = _ptr(self.state)
+        if streaming_only:
+            self.state.zero_()
+            self.big_segments = self.B * self.nseg
+            state_for_skip = None
+        else:
+            check(lib.imgan_dcd_segments(_ptr(lab), _ptr(labels), *shape, 1 if use_hash else 0,
+                                         cseed, _ptr(centres), _ptr(self.assign), _ptr(self.state),
+                                         _ptr(self.stats), _ptr(self.bbox), _ptr(self.n_big),
+                                         int(max_rounds), _stream()))
+            self.big_segments = int(self.n_big.item())
+        self.rounds_run = 0
+        if self.big_segments == 0:
+            return centres, self.assign
+        if use_hash:
+            if self.slots is None:
+                self.slots = torch.empty((self.B, self.nseg, self.k), dtype=torch.int64,
+                                         device=self.state.device)
+            check(lib.imgan_dcd_init_hash(_ptr(lab), _ptr(labels), *shape, cseed, _ptr(centres),
+                                          _ptr(self.slots), state_for_skip, _stream()))
         r = 0
         while r < max_rounds:
-            check(lib.imgan_dcd_kmeans_round(_ptr(lab), _ptr(labels), self.B, self.H, self.W,
-                                             self.nseg, self.k, _ptr(centres), _ptr(self.assign),
-                                             _ptr(self.state), 1 if r == 0 else 0,
+            check(lib.imgan_dcd_kmeans_round(_ptr(lab), _ptr(labels), *shape, _ptr(centres),
+                                             _ptr(self.assign), _ptr(self.state),
+                                             1 if (r == 0 and streaming_only) else 0,
                                              _ptr(self.active), _stream()))
             r += 1
             if r % check_every == 0 and int(self.active.item()) == 0:
@@ -316,7 +349,7 @@ class DcdPlan(object):
                                    _ptr(done), _stream()))
         return rounds, done
 
-    def statistics(self, lab, labels):
+    def statistics(self, lab, labels, streaming_only=False):
         """uint64 [B,nseg,k,8]: count, sum c0..c2, sum of squares c0..c2, largest component."""
         lab = as_batch(_dev(lab, torch.uint8, "lab"))
         if labels.dim() == 2:
@@ -326,7 +359,7 @@ class DcdPlan(object):
                                        device=self.state.device)
         check(lib.imgan_dcd_stats(_ptr(lab), _ptr(labels), _ptr(self.assign), self.B, self.H,
                                   self.W, self.nseg, self.k, _ptr(self.stats), _ptr(self.scratch),
-                                  _stream()))
+                                  None if streaming_only else _ptr(self.state), _stream()))
         return self.stats
 
 

@@ -27,7 +27,6 @@ class FullPipeline(object):
         self.desc = ops.DescriptorPlan(B, H, W, csd_bins)
         self.dcd = ops.DcdPlan(B, H, W, self.n, self.k)
         self.centres = torch.empty((self.B, self.n, self.k, 3), dtype=torch.float32, device=dev)
-        self.slots = torch.empty((self.B, self.n, self.k), dtype=torch.int64, device=dev)
         self.features = torch.empty((self.B, self.n, self.k, 8), dtype=torch.float32, device=dev)
         self.assign_events = []
         self.dcd_rounds_run = 0
@@ -47,10 +46,7 @@ class FullPipeline(object):
     def run_dcd(self):
         labels = self.slic.labels
         p = ops._ptr
-        check(lib.imgan_dcd_init_hash(p(self.lab), p(labels), self.B, self.H, self.W, self.n, self.k,
-                                      ctypes.c_uint32(self.seed), p(self.centres), p(self.slots),
-                                      ops._stream()))
-        self.dcd.kmeans(self.lab, labels, self.centres, max_rounds=self.max_rounds,
+        self.dcd.kmeans(self.lab, labels, self.centres, seed=self.seed, max_rounds=self.max_rounds,
                         check_every=self.check_every)
         self.dcd_rounds_run = self.dcd.rounds_run
         stats = self.dcd.statistics(self.lab, labels)

@@ -78,13 +78,14 @@ class MPEG7Descriptors(object):
             out[j] = [mean, var, n / float(nseg_pixels), int(stats[j, 7]) / float(n)]
         return out
 
-    def _run_dcd(self, label_map, nseg, k, centres):
+    def _run_dcd(self, label_map, nseg, k, centres, streaming_only=False):
         H, W = label_map.shape
         plan = ops.DcdPlan(1, H, W, nseg, k)
         dev_labels = torch.from_numpy(np.ascontiguousarray(label_map)).cuda().unsqueeze(0)
         dev_centres = torch.from_numpy(np.ascontiguousarray(centres, dtype=np.float32)).cuda()
-        plan.kmeans(self._dev_lab, dev_labels, dev_centres.view(1, nseg, k, 3))
-        stats = plan.statistics(self._dev_lab, dev_labels)[0].cpu().numpy()
+        plan.kmeans(self._dev_lab, dev_labels, dev_centres.view(1, nseg, k, 3),
+                    streaming_only=streaming_only)
+        stats = plan.statistics(self._dev_lab, dev_labels, streaming_only)[0].cpu().numpy()
         rounds, _ = plan.rounds()
         return stats, dev_centres.cpu().numpy().reshape(nseg, k, 3), rounds[0].cpu().numpy()
 

@@ -149,10 +149,26 @@ int imgan_dcd_rounds(const void* state, int B, int nseg, int k, int32_t* rounds_
 /* Device-side, reproducible stand-in for the reference's unseeded random.sample(segment, k)
  * (mpeg7Descriptors.py:79): pixel p competes for slot hash(p, seed) % k of its segment and the
  * smallest (hash, p) wins, giving k distinct pixels per segment.  centres: float32
- * [B][nseg][k][3] out; slots: uint64 [B][nseg][k] scratch (winning hash<<32 | pixel). */
+ * [B][nseg][k][3] out; slots: uint64 [B][nseg][k] scratch (winning hash<<32 | pixel).
+ * state: NULL, or the loop state after imgan_dcd_segments (segments done there are skipped). */
 int imgan_dcd_init_hash(const uint8_t* lab, const int32_t* labels, int B, int H, int W, int nseg,
-                        int k, uint32_t seed, float* centres, uint64_t* slots,
+                        int k, uint32_t seed, float* centres, uint64_t* slots, const void* state,
                         imgan_stream_t stream);
+
+/* The whole loop of mpeg7Descriptors.py:76-116 for every segment that fits on chip: one
+ * workgroup gathers a segment's pixels into LDS, runs its Lloyd rounds there until the
+ * reference's stop rule and writes centres, the per-pixel assignment, the per-segment round
+ * count (state) and the integer statistics count / sums / sums of squares (stats slots 0-6).
+ * use_hash_init != 0 samples the initial centres as imgan_dcd_init_hash does, otherwise
+ * `centres` holds them on entry.  Segments too large for LDS are left untouched and counted in
+ * n_big_out (device int32): the caller finishes them with imgan_dcd_init_hash /
+ * imgan_dcd_kmeans_round, which skip the segments already done.  `state` needs no
+ * initialisation; bbox_scratch: imgan_dcd_bbox_bytes() bytes. */
+size_t imgan_dcd_bbox_bytes(int B, int nseg);
+int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int B, int H, int W, int nseg,
+                       int k, int use_hash_init, uint32_t seed, float* centres, uint8_t* assign,
+                       void* state, uint64_t* stats, void* bbox_scratch, int32_t* n_big_out,
+                       int max_rounds, imgan_stream_t stream);
 
 /* mpeg7Descriptors.py:114-129 from the integer statistics: features float32 [B][nseg][k][8] =
  * mean(3), population variance(3), percentage, spatial coherence. */
@@ -161,9 +177,10 @@ int imgan_dcd_features(const uint64_t* stats, const float* centres, int B, int n
 
 /* mpeg7Descriptors.py:110-129: per (segment, colour) integer statistics.
  * stats: uint64 [B][nseg][k][8] = count, sum c0..c2, sum of squares c0..c2,
- * size of the largest 8-connected component.  scratch: int32 [B][H][W] x 3. */
+ * size of the largest 8-connected component.  scratch: int32 [B][H][W] x 3.  state: the loop
+ * state (keeps the sums imgan_dcd_segments already wrote) or NULL (recompute everything). */
 int imgan_dcd_stats(const uint8_t* lab, const int32_t* labels, const uint8_t* assign, int B, int H,
-                    int W, int nseg, int k, uint64_t* stats, int32_t* scratch,
+                    int W, int nseg, int k, uint64_t* stats, int32_t* scratch, const void* state,
                     imgan_stream_t stream);
 
 /* ---- MPEG-7 colour layout / edge histogram / colour structure ----------------

@@ -230,3 +230,44 @@ def test_full_pipeline_batch_matches_oracle():
                 else:
                     assert np.allclose(g[3:6], wv, rtol=1e-4, atol=1e-6), (b, s, j)
                 assert np.isclose(g[6], wp, rtol=1e-6) and np.isclose(g[7], wc, rtol=1e-6)
+
+
+def test_dcd_lds_path_equals_streaming_path():
+    """The LDS-resident segment kernel and the streaming rounds are two schedules of the same
+    arithmetic: centres, assignment, statistics and round counts must be identical, also when
+    some segments are too large for LDS and take the streaming rounds."""
+    torch = _torch()
+    from imgan import ops
+    from oracle.color import bgr2lab_u8
+    H, W, k = 200, 260, 8
+    img = voronoi_image(H, W, 14, seed=61, noise=15.0)
+    lab = torch.from_numpy(bgr2lab_u8(img)).cuda().unsqueeze(0)
+    # 30 small square segments + one large segment (> LDS capacity) + unlabelled border
+    labels = np.full((H, W), -1, dtype=np.int32)
+    labels[0:150, 0:240] = 30
+    sid = 0
+    for gy in range(5):
+        for gx in range(6):
+            labels[150 + gy * 9:150 + gy * 9 + 9, gx * 40:gx * 40 + 37] = sid
+            sid += 1
+    dl = torch.from_numpy(labels).cuda().unsqueeze(0)
+    rng = np.random.RandomState(4)
+    cen0 = np.zeros((1, 31, k, 3), dtype=np.float32)
+    labf = bgr2lab_u8(img).reshape(-1, 3)
+    for s in range(31):
+        idx = np.nonzero(labels.ravel() == s)[0]
+        cen0[0, s] = labf[rng.choice(idx, k, replace=False)]
+    out = []
+    for streaming in (False, True):
+        plan = ops.DcdPlan(1, H, W, 31, k)
+        cen = torch.from_numpy(cen0.copy()).cuda()
+        plan.kmeans(lab, dl, cen, streaming_only=streaming)
+        stats = plan.statistics(lab, dl, streaming_only=streaming)
+        rounds, done = plan.rounds()
+        out.append((cen.cpu().numpy(), plan.assign.cpu().numpy().copy(), stats.cpu().numpy().copy(),
+                    rounds.cpu().numpy(), plan.big_segments))
+    assert out[0][4] == 1 and out[1][4] == 31            # one segment exceeded the LDS capacity
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])
+    assert np.array_equal(out[0][3], out[1][3])
