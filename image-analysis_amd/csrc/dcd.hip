@@ -190,10 +190,11 @@ __global__ __launch_bounds__(256) void dcd_values_kernel(
         int s = labels[gp];
         int j = assign[gp];
         int key = (s >= 0 && s < nseg && j < k) ? s * k + j : -1;
+        // segments finished on chip have all eight statistics already: leave them out
+        if (key >= 0 && seg && seg[(size_t)b * nseg + s].handled) key = -1;
         values[gp] = key;
         sizes[gp] = 0;
         if (key < 0) continue;
-        if (seg && seg[(size_t)b * nseg + s].handled) continue;   // sums already final
         const uint8_t* q = lab + gp * 3;
         uint32_t u0 = q[0], u1 = q[1], u2 = q[2];
         uint32_t v[7] = {1u, u0, u1, u2, u0 * u0, u1 * u1, u2 * u2};
@@ -220,10 +221,7 @@ __global__ void dcd_zero_stats_kernel(unsigned long long* __restrict__ stats, in
     if (t >= nsegs * k) return;
     int s = t / k;
     unsigned long long* a = stats + (size_t)t * 8;
-    if (seg && seg[s].handled) {
-        a[7] = 0ull;                      // only the largest-component slot is recomputed
-        return;
-    }
+    if (seg && seg[s].handled) return;      // finished on chip, statistics included
     for (int f = 0; f < 8; ++f) a[f] = 0ull;
 }
 

@@ -21,37 +21,39 @@ using namespace imgan_dcd;
 
 namespace {
 
-constexpr int SEG_THREADS = 512;
-constexpr int SEG_CAP = 11776;              // pixels of one segment held in LDS (6 B each)
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
-}
-
-// bbox: int [nsegs][5] = xmin, ymin, xmax, ymax, count (host pre-fills mins with INT_MAX)
-__global__ __launch_bounds__(256) void seg_bbox_kernel(const int32_t* __restrict__ labels, int H,
-                                                       int W, int nseg, int* __restrict__ bbox) {
-    const int b = blockIdx.z;
-    const int y = blockIdx.y;
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    int pending = -1;
-    if (x < W) {
-        int l = labels[((size_t)b * H + y) * W + x];
-        if (l >= 0 && l < nseg) pending = l;
+// Two capacity tiers: most segments (superpixels) fit the small tier, which leaves room for
+// two workgroups per CU; the few larger ones are retried by the large tier (one workgroup per
+// CU); only what exceeds that goes to the streaming path.
+#ifdef IMGAN_SEG_TIMING
+// phase clocks of thread 0, summed over blocks (tools/seg_timing.py; never built into the product)
+__device__ unsigned long long seg_timing[16];
+#define SEG_MARK(i)                                                         \
+    if (tid == 0) {                                                         \
+        unsigned long long now_ = wall_clock64();                           \
+        atomicAdd(&seg_timing[i], now_ - t_last_);                          \
+        t_last_ = now_;                                                     \
     }
-    const int lane = threadIdx.x & 63;
+#else
+#define SEG_MARK(i)
+#endif
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int CAP_SMALL = 11776, THREADS_SMALL = 512;       // 6 B of LDS per pixel
+constexpr int CAP_LARGE = 22528, THREADS_LARGE = 1024;     // >= 4 S^2 of the 1080p / K=400 grid
+// The small tier packs {count, sum0} and {sum1, sum2} into 16-bit halves of two words per
+// lane-private copy: a copy sees at most CAP / 64 pixels, and 184 * 255 < 65536.
+static_assert((CAP_SMALL / 64) * 255 < 65536, "packed accumulators would overflow");
+
+// bbox: int [nsegs][4] = xmin, ymin, xmax, ymax.  One block = 256 columns x BBOX_ROWS rows
+// (a block per row was bound by the workgroup dispatch rate, not by memory).  Each wave walks
+// down its 64 columns; per row the extremes of every label run come from a ballot, and an
+// atomic is only issued when it can still move the stored extreme (the pre-read may be stale,
+// which only costs a redundant atomic).
+constexpr int BBOX_ROWS = 32;
+
+__device__ __forceinline__ void bbox_row(int pending, int x, int y, int lane, int nseg, int b,
+                                         int* __restrict__ bbox) {
     while (true) {
         unsigned long long act = __ballot(pending >= 0);
         if (act == 0ull) break;
@@ -62,40 +64,106 @@ __global__ __launch_bounds__(256) void seg_bbox_kernel(const int32_t* __restrict
         // lanes are consecutive columns of one row: the extremes are the first / last set bit
         int first = __ffsll((long long)who) - 1, last = 63 - __clzll((long long)who);
         if (lane == leader) {
-            int* bb = bbox + ((size_t)b * nseg + cur) * 5;
+            int* bb = bbox + ((size_t)b * nseg + cur) * 4;
             int xb = x - lane;
-            atomicMin(&bb[0], xb + first);
-            atomicMin(&bb[1], y);
-            atomicMax(&bb[2], xb + last);
-            atomicMax(&bb[3], y);
-            atomicAdd(&bb[4], __popcll(who));
+            if (xb + first < bb[0]) atomicMin(&bb[0], xb + first);
+            if (y < bb[1]) atomicMin(&bb[1], y);
+            if (xb + last > bb[2]) atomicMax(&bb[2], xb + last);
+            if (y > bb[3]) atomicMax(&bb[3], y);
         }
         if (mine) pending = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_bbox_kernel(const int32_t* __restrict__ labels, int H,
+                                                       int W, int nseg, int* __restrict__ bbox) {
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * BBOX_ROWS;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int xc = x < W ? x : W - 1;
+    const int32_t* col = labels + (size_t)b * H * W + xc;
+    for (int r = 0; r < BBOX_ROWS; r += 4) {
+        int l[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                  // 4 rows in flight, clamped not branched
+            int y = y0 + r + u;
+            l[u] = col[(size_t)(y < H ? y : H - 1) * W];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int y = y0 + r + u;
+            bool ok = x < W && y < H && l[u] >= 0 && l[u] < nseg;
+            bbox_row(ok ? l[u] : -1, x, y, lane, nseg, b, bbox);
+        }
     }
 }
 
 __global__ void seg_bbox_init_kernel(int* __restrict__ bbox, int nsegs) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nsegs) return;
-    int* bb = bbox + (size_t)t * 5;
+    int* bb = bbox + (size_t)t * 4;
     bb[0] = 0x7fffffff;
     bb[1] = 0x7fffffff;
     bb[2] = -1;
     bb[3] = -1;
-    bb[4] = 0;
 }
 
-template <int KM>
-__global__ __launch_bounds__(SEG_THREADS) void dcd_segment_kernel(
+// ---- union-find on 16-bit parents in LDS (the hardware has no 16-bit LDS atomics: a
+// compare-and-swap on the containing word stands in for atomicMin)
+__device__ __forceinline__ uint32_t find16(const volatile uint16_t* par, uint32_t a) {
+    while (true) {
+        uint32_t p = par[a];
+        if (p == a) return a;
+        a = p;
+    }
+}
+
+__device__ __forceinline__ uint32_t atomic_min16(uint16_t* par, uint32_t idx, uint32_t val) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(par) + (idx >> 1);
+    const uint32_t sh = (idx & 1u) * 16u;
+    uint32_t old = *reinterpret_cast<volatile uint32_t*>(w);
+    while (true) {
+        const uint32_t cur = (old >> sh) & 0xffffu;
+        if (cur <= val) return cur;
+        const uint32_t nw = (old & ~(0xffffu << sh)) | (val << sh);
+        const uint32_t prev = atomicCAS(w, old, nw);
+        if (prev == old) return cur;
+        old = prev;
+    }
+}
+
+__device__ __forceinline__ void unite16(uint16_t* par, uint32_t a, uint32_t b) {
+    while (true) {
+        a = find16(par, a);
+        b = find16(par, b);
+        if (a == b) return;
+        if (a < b) {
+            uint32_t t = a;
+            a = b;
+            b = t;
+        }
+        const uint32_t old = atomic_min16(par, a, b);      // hang the larger root under the smaller
+        if (old == a) return;
+        a = old;                                           // somebody re-parented a meanwhile
+    }
+}
+
+// FIRST: the small tier visits every segment; the large tier only those left with handled == 0.
+template <int KM, int CAP, int THREADS, bool FIRST>
+__global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
     const uint8_t* __restrict__ lab, const int32_t* __restrict__ labels, int H, int W, int nseg,
     int k, int use_hash, uint32_t seed, float* __restrict__ centres, uint8_t* __restrict__ assign,
     SegState* __restrict__ seg, unsigned long long* __restrict__ stats,
     const int* __restrict__ bbox, int* __restrict__ big_count, int max_rounds) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* pix = reinterpret_cast<uint32_t*>(smem);                    // Lab | assign << 24
-    uint16_t* pos = reinterpret_cast<uint16_t*>(pix + SEG_CAP);           // offset in the bbox
-    uint32_t* acc = reinterpret_cast<uint32_t*>(pos + SEG_CAP);           // [KM*3][64] lane-private
-    unsigned long long* slots = reinterpret_cast<unsigned long long*>(acc + KM * 3 * 64);
+    uint16_t* pos = reinterpret_cast<uint16_t*>(pix + CAP);               // offset in the bbox
+    constexpr bool PACKED = (CAP / 64) * 255 < 65536;
+    constexpr int WORDS = PACKED ? 2 : 4;                                 // per cluster and copy
+    constexpr int ACCW = WORDS > 3 ? WORDS : 3;                           // statistics use 3
+    uint32_t* acc = reinterpret_cast<uint32_t*>(pos + CAP);               // [KM*ACCW][64] lane-private
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(acc + KM * ACCW * 64);
     float* cen = reinterpret_cast<float*>(slots + KM);                   // [KM][3]
     float* old = cen + KM * 3;                                            // [KM][3]
     uint32_t* red = reinterpret_cast<uint32_t*>(old + KM * 3);           // [KM][4] count, sums
@@ -106,8 +174,12 @@ __global__ __launch_bounds__(SEG_THREADS) void dcd_segment_kernel(
     const int b = blockIdx.y, s = blockIdx.x;
     const size_t gs = (size_t)b * nseg + s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int* bb = bbox + gs * 5;
-    const int xmin = bb[0], ymin = bb[1], xmax = bb[2], ymax = bb[3], cnt = bb[4];
+#ifdef IMGAN_SEG_TIMING
+    unsigned long long t_last_ = wall_clock64();
+#endif
+    if (!FIRST && seg[gs].handled) return;
+    const int* bb = bbox + gs * 4;
+    const int xmin = bb[0], ymin = bb[1], xmax = bb[2], ymax = bb[3];
     SegState st;
     st.old_sum = 0.0;
     st.done = 1;
@@ -115,44 +187,94 @@ __global__ __launch_bounds__(SEG_THREADS) void dcd_segment_kernel(
     st.handled = 1;
     st.pad = 0;
     unsigned long long* out = stats + gs * k * 8;
-    if (cnt == 0) {                                     // segment id without pixels
+    if (xmax < 0) {                                     // segment id without pixels
         if (tid == 0) seg[gs] = st;
-        for (int i = tid; i < k * 8; i += SEG_THREADS) out[i] = 0ull;
+        for (int i = tid; i < k * 8; i += THREADS) out[i] = 0ull;
         return;
     }
     const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
-    if (cnt > SEG_CAP || (long long)bw * bh > 65535) {  // too large: the streaming path takes it
+    const int area = bw * bh;
+    const size_t img = (size_t)b * H * W;
+    // positions are kept as 16-bit offsets, and the coherence pass lays a 3-byte cell grid of
+    // the box over the pixel store
+    bool big = (long long)bw * bh > 65535 || (long long)bw * bh * 3 + 8 > (long long)CAP * 6;
+    if (!big) {
+        if (tid == 0) s_n = 0;
+        if (tid < KM) slots[tid] = ~0ull;
+        __syncthreads();
+        SEG_MARK(0)
+        // ---- gather the segment's pixels.  Every load of a batch is issued before the first
+        // use: addresses are clamped into the box instead of branching around the loads (a
+        // load under a branch makes the compiler wait for it at the join, which serialises
+        // the batch and leaves the gather bound by 8 memory latencies per step).
+        const float inv_bw = 1.0f / (float)bw;
+        for (int i0 = 0; i0 < area; i0 += THREADS * 4) {
+            int lbl[4], off[4];
+            uint32_t pp[4], r0[4], r1[4], r2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * THREADS + tid;
+                off[u] = i;
+                const int ic = i < area ? i : area - 1;
+                int yy = (int)((float)ic * inv_bw);
+                int xx = ic - yy * bw;
+                yy += (xx >= bw) - (xx < 0);            // the float quotient can be off by one
+                xx = ic - yy * bw;
+                pp[u] = (uint32_t)((ymin + yy) * W + xmin + xx);
+                lbl[u] = labels[img + pp[u]];
+                const uint8_t* q = lab + (img + pp[u]) * 3;
+                r0[u] = q[0];
+                r1[u] = q[1];
+                r2[u] = q[2];
+            }
+            uint32_t v[4];
+            int slot[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (off[u] >= area) lbl[u] = -2;
+                const bool m = lbl[u] == s;
+                // one LDS atomic per wave: the leader reserves a run of slots
+                const unsigned long long who = __ballot(m);
+                int base = 0;
+                if (who) {
+                    const int leader = __ffsll((long long)who) - 1;
+                    if (lane == leader) base = atomicAdd(&s_n, __popcll(who));
+                    base = __shfl(base, leader);
+                }
+                slot[u] = base + __popcll(who & ((1ull << lane) - 1ull));
+                v[u] = r0[u] | (r1[u] << 8) | (r2[u] << 16);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (lbl[u] != s) continue;
+                if (slot[u] < CAP) {
+                    pix[slot[u]] = v[u];
+                    pos[slot[u]] = (uint16_t)off[u];
+                }
+                if (use_hash) {
+                    // stand-in for random.sample (:79): slot h % k goes to the smallest (h, p)
+                    const uint32_t h = mix32(pp[u] * 0x9e3779b1u + seed);
+                    const unsigned long long key =
+                        ((unsigned long long)h << 32) | (unsigned long long)pp[u];
+                    unsigned long long* sl = &slots[h % (uint32_t)k];
+                    if (key < *sl) atomicMin(sl, key);
+                }
+            }
+        }
+        SEG_MARK(7)
+        __syncthreads();
+        SEG_MARK(1)
+        big = s_n > CAP;
+    }
+    if (big) {                                          // too large for this tier
         if (tid == 0) {
             st.done = 0;
             st.handled = 0;
             seg[gs] = st;
-            atomicAdd(big_count, 1);
+            if (!FIRST) atomicAdd(big_count, 1);        // left to the streaming path
         }
         return;
     }
-    const size_t img = (size_t)b * H * W;
-    if (tid == 0) s_n = 0;
-    if (tid < KM) slots[tid] = ~0ull;
-    __syncthreads();
-
-    // ---- gather the segment's pixels (rows by wave, columns by lane) + sample the init pixels
-    for (int yy = wave; yy < bh; yy += SEG_THREADS / 64)
-        for (int xx = lane; xx < bw; xx += 64) {
-            const size_t p = (size_t)(ymin + yy) * W + xmin + xx;
-            if (labels[img + p] != s) continue;
-            const uint8_t* q = lab + (img + p) * 3;
-            const uint32_t v = q[0] | (q[1] << 8) | (q[2] << 16);
-            const int slot = atomicAdd(&s_n, 1);
-            pix[slot] = v;
-            pos[slot] = (uint16_t)(yy * bw + xx);
-            if (use_hash) {
-                // stand-in for random.sample (:79): slot h % k goes to the smallest (h, p)
-                const uint32_t h = mix32((uint32_t)p * 0x9e3779b1u + seed);
-                atomicMin(&slots[h % (uint32_t)k],
-                          ((unsigned long long)h << 32) | (unsigned long long)(uint32_t)p);
-            }
-        }
-    __syncthreads();
     const int n = s_n;
 
     // ---- initial centres
@@ -172,108 +294,162 @@ __global__ __launch_bounds__(SEG_THREADS) void dcd_segment_kernel(
             c1 = src[1];
             c2 = src[2];
         }
-        cen[tid * 3] = c0;
-        cen[tid * 3 + 1] = c1;
-        cen[tid * 3 + 2] = c2;
-        old[tid * 3] = old[tid * 3 + 1] = old[tid * 3 + 2] = 0.f;
+        cen[tid] = c0;
+        cen[KM + tid] = c1;
+        cen[2 * KM + tid] = c2;
+        old[tid] = old[KM + tid] = old[2 * KM + tid] = 0.f;
+    } else if (tid < KM) {
+        // unused slots sit far away from every 8-bit colour, so the loop over all KM slots
+        // never picks them and needs no bound check
+        cen[tid] = cen[KM + tid] = cen[2 * KM + tid] = 1.0e18f;
     }
     if (tid == 0) s_done = 0;
-    double old_sum = 0.0;              // only thread 0's copy is used
+    double old_sum = 0.0;              // only lane 0 of wave 0 uses its copy
     int rounds = 0;
     const float NEAR = 1.0f - 9.5367431640625e-07f;       // 1 - 2^-20
 
     // ---- Lloyd rounds (:85-107)
     while (true) {
-        for (int i = tid; i < k * 2 * 64; i += SEG_THREADS) acc[i] = 0;
+        for (int i = tid; i < k * WORDS * 64; i += THREADS) acc[i] = 0;
         __syncthreads();
-        float c[KM][3];
+        SEG_MARK(6)
+        // centres in registers, two per packed fp32 operand (v_pk_add/mul_f32: IEEE per half)
+        f32x2 c0[KM / 2], c1[KM / 2], c2[KM / 2];
 #pragma unroll
-        for (int j = 0; j < KM; ++j)
-            if (j < k) {
-                c[j][0] = cen[j * 3];
-                c[j][1] = cen[j * 3 + 1];
-                c[j][2] = cen[j * 3 + 2];
-            }
-        for (int i = tid; i < n; i += SEG_THREADS) {
+        for (int jj = 0; jj < KM / 2; ++jj) {
+            c0[jj] = *reinterpret_cast<const f32x2*>(cen + 2 * jj);
+            c1[jj] = *reinterpret_cast<const f32x2*>(cen + KM + 2 * jj);
+            c2[jj] = *reinterpret_cast<const f32x2*>(cen + 2 * KM + 2 * jj);
+        }
+        for (int i = tid; i < n; i += THREADS) {
             const uint32_t v = pix[i];
             const uint32_t u0 = v & 255u, u1 = (v >> 8) & 255u, u2 = (v >> 16) & 255u;
             const float f0 = (float)u0, f1 = (float)u1, f2 = (float)u2;
-            float best2 = __builtin_inff(), bestn = __builtin_inff();
+            // The reference compares sqrt-rounded distances with '<' (:88-91): the winner is the
+            // first minimum of sqrt_rn(q).  The first minimum of q itself is the same cluster
+            // unless another q lies within a few ulp of the smallest one, so the fast loop
+            // tracks the two smallest q and only a near tie replays the literal rule.
+            const f32x2 F0 = {f0, f0}, F1 = {f1, f1}, F2 = {f2, f2};
+            float best = __builtin_inff(), second = __builtin_inff();
             int bi = 0;
 #pragma unroll
-            for (int j = 0; j < KM; ++j)
-                if (j < k) {
-                    const float d0 = f0 - c[j][0], d1 = f1 - c[j][1], d2 = f2 - c[j][2];
-                    const float q2 = __fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)),
-                                               __fmul_rn(d2, d2));
-                    bool take = q2 < bestn;                 // clearly smaller after the sqrt too
-                    if (!take && q2 < best2)                // near tie: decide on the rounded sqrt
-                        take = __fsqrt_rn(q2) < __fsqrt_rn(best2);
-                    best2 = take ? q2 : best2;
-                    bestn = take ? __fmul_rn(q2, NEAR) : bestn;
-                    bi = take ? j : bi;
+            for (int jj = 0; jj < KM / 2; ++jj) {
+                const f32x2 d0 = F0 - c0[jj], d1 = F1 - c1[jj], d2 = F2 - c2[jj];
+                const f32x2 q = (d0 * d0 + d1 * d1) + d2 * d2;
+                second = __builtin_amdgcn_fmed3f(q.x, best, second);
+                bi = q.x < best ? 2 * jj : bi;
+                best = fminf(best, q.x);
+                second = __builtin_amdgcn_fmed3f(q.y, best, second);
+                bi = q.y < best ? 2 * jj + 1 : bi;
+                best = fminf(best, q.y);
+            }
+            if (__builtin_expect(__fmul_rn(second, NEAR) < best, 0)) {
+                float bs = __builtin_inff();
+                bi = 0;
+                for (int j = 0; j < k; ++j) {
+                    const float e0 = __fsub_rn(f0, cen[j]), e1 = __fsub_rn(f1, cen[KM + j]),
+                                e2 = __fsub_rn(f2, cen[2 * KM + j]);
+                    const float sq = __fsqrt_rn(__fadd_rn(
+                        __fadd_rn(__fmul_rn(e0, e0), __fmul_rn(e1, e1)), __fmul_rn(e2, e2)));
+                    if (sq < bs) {
+                        bs = sq;
+                        bi = j;
+                    }
                 }
+            }
             pix[i] = (v & 0xffffffu) | ((uint32_t)bi << 24);
-            atomicAdd(&acc[(bi * 2) * 64 + lane], 1u | (u0 << 16));
-            atomicAdd(&acc[(bi * 2 + 1) * 64 + lane], u1 | (u2 << 16));
+            if (PACKED) {
+                atomicAdd(&acc[(bi * 2) * 64 + lane], 1u | (u0 << 16));
+                atomicAdd(&acc[(bi * 2 + 1) * 64 + lane], u1 | (u2 << 16));
+            } else {
+                atomicAdd(&acc[(bi * 4) * 64 + lane], 1u);
+                atomicAdd(&acc[(bi * 4 + 1) * 64 + lane], u0);
+                atomicAdd(&acc[(bi * 4 + 2) * 64 + lane], u1);
+                atomicAdd(&acc[(bi * 4 + 3) * 64 + lane], u2);
+            }
         }
         __syncthreads();
+        SEG_MARK(2)
         // reduce the 64 lane-private copies: 4 lanes per (cluster, word) row, 16 copies each
-        if (tid < k * 2 * 4) {
+        if (tid < k * WORDS * 4) {
             const int row = tid >> 2, q = tid & 3;
             uint32_t lo = 0, hi = 0;
             const uint4* src = reinterpret_cast<const uint4*>(acc + row * 64 + q * 16);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 uint4 w4 = src[t];
-                lo += (w4.x & 0xffffu) + (w4.y & 0xffffu) + (w4.z & 0xffffu) + (w4.w & 0xffffu);
-                hi += (w4.x >> 16) + (w4.y >> 16) + (w4.z >> 16) + (w4.w >> 16);
+                if (PACKED) {
+                    lo += (w4.x & 0xffffu) + (w4.y & 0xffffu) + (w4.z & 0xffffu) + (w4.w & 0xffffu);
+                    hi += (w4.x >> 16) + (w4.y >> 16) + (w4.z >> 16) + (w4.w >> 16);
+                } else {
+                    lo += w4.x + w4.y + w4.z + w4.w;
+                }
             }
             lo += __shfl_xor(lo, 1);
             hi += __shfl_xor(hi, 1);
             lo += __shfl_xor(lo, 2);
             hi += __shfl_xor(hi, 2);
             if (q == 0) {
-                red[row * 2] = lo;          // row = cluster*2 + word: {count, s0}, {s1, s2}
-                red[row * 2 + 1] = hi;
+                if (PACKED) {               // row = cluster*2 + word: {count, s0}, {s1, s2}
+                    red[row * 2] = lo;
+                    red[row * 2 + 1] = hi;
+                } else {                    // row = cluster*4 + {count, s0, s1, s2}
+                    red[row] = lo;
+                }
             }
         }
         __syncthreads();
-        if (tid == 0) {                     // centre update + stop rule (:93-107)
-            float sh0 = 0.f, sh1 = 0.f, sh2 = 0.f;
-            for (int j = 0; j < k; ++j) {
-                const uint32_t nj = red[j * 4];
-                float c0 = cen[j * 3], c1 = cen[j * 3 + 1], c2 = cen[j * 3 + 2];
+        SEG_MARK(3)
+        if (wave == 0) {                    // centre update + stop rule (:93-107)
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+            if (lane < k) {
+                const uint32_t nj = red[lane * 4];
+                c0 = cen[lane];
+                c1 = cen[KM + lane];
+                c2 = cen[2 * KM + lane];
                 if (nj) {
                     const float fn = (float)nj;
-                    c0 = __fdiv_rn((float)red[j * 4 + 1], fn);
-                    c1 = __fdiv_rn((float)red[j * 4 + 2], fn);
-                    c2 = __fdiv_rn((float)red[j * 4 + 3], fn);
-                    cen[j * 3] = c0;
-                    cen[j * 3 + 1] = c1;
-                    cen[j * 3 + 2] = c2;
+                    c0 = __fdiv_rn((float)red[lane * 4 + 1], fn);
+                    c1 = __fdiv_rn((float)red[lane * 4 + 2], fn);
+                    c2 = __fdiv_rn((float)red[lane * 4 + 3], fn);
+                    cen[lane] = c0;
+                    cen[KM + lane] = c1;
+                    cen[2 * KM + lane] = c2;
                 }
-                sh0 = __fadd_rn(sh0, fabsf(__fsub_rn(c0, old[j * 3])));
-                sh1 = __fadd_rn(sh1, fabsf(__fsub_rn(c1, old[j * 3 + 1])));
-                sh2 = __fadd_rn(sh2, fabsf(__fsub_rn(c2, old[j * 3 + 2])));
+                a0 = fabsf(__fsub_rn(c0, old[lane]));
+                a1 = fabsf(__fsub_rn(c1, old[KM + lane]));
+                a2 = fabsf(__fsub_rn(c2, old[2 * KM + lane]));
+            }
+            float sh0 = 0.f, sh1 = 0.f, sh2 = 0.f;      // float32 sums in cluster order (:102)
+            for (int j = 0; j < k; ++j) {
+                sh0 = __fadd_rn(sh0, __shfl(a0, j));
+                sh1 = __fadd_rn(sh1, __shfl(a1, j));
+                sh2 = __fadd_rn(sh2, __shfl(a2, j));
             }
             const double cent_sum = ((double)sh0 + (double)sh1) + (double)sh2;
             rounds += 1;
-            if (fabs(old_sum - cent_sum) < 0.1 || rounds >= max_rounds) {
-                s_done = rounds;
-            } else {
-                for (int j = 0; j < 3 * k; ++j) old[j] = cen[j];
+            const bool stop = fabs(old_sum - cent_sum) < 0.1 || rounds >= max_rounds;
+            if (!stop) {
                 old_sum = cent_sum;
+                if (lane < k) {
+                    old[lane] = c0;
+                    old[KM + lane] = c1;
+                    old[2 * KM + lane] = c2;
+                }
+            } else if (lane == 0) {
+                s_done = rounds;
             }
         }
         __syncthreads();
+        SEG_MARK(4)
         if (s_done) break;
     }
 
     // ---- statistics (:110-116): count / sums come from the last round, squares need a pass
-    for (int i = tid; i < k * 3 * 64; i += SEG_THREADS) acc[i] = 0;
+    for (int i = tid; i < k * 3 * 64; i += THREADS) acc[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += SEG_THREADS) {
+    const float inv_bw = 1.0f / (float)bw;
+    for (int i = tid; i < n; i += THREADS) {
         const uint32_t v = pix[i];
         const uint32_t u0 = v & 255u, u1 = (v >> 8) & 255u, u2 = (v >> 16) & 255u, bi = v >> 24;
         atomicAdd(&acc[(bi * 3) * 64 + lane], u0 * u0);
@@ -281,10 +457,19 @@ __global__ __launch_bounds__(SEG_THREADS) void dcd_segment_kernel(
         atomicAdd(&acc[(bi * 3 + 2) * 64 + lane], u2 * u2);
         // assignment back to the image
         const int o = pos[i];
-        const int yy = o / bw, xx = o - yy * bw;
+        int yy = (int)((float)o * inv_bw);
+        int xx = o - yy * bw;
+        if (xx < 0) {
+            --yy;
+            xx += bw;
+        } else if (xx >= bw) {
+            ++yy;
+            xx -= bw;
+        }
         assign[img + (size_t)(ymin + yy) * W + xmin + xx] = (uint8_t)bi;
     }
     __syncthreads();
+    SEG_MARK(5)
     if (tid < k * 3 * 4) {
         const int row = tid >> 2, q = tid & 3;
         unsigned long long sum = 0;
@@ -298,16 +483,91 @@ __global__ __launch_bounds__(SEG_THREADS) void dcd_segment_kernel(
         sum += __shfl_xor(sum, 2);
         if (q == 0) out[(row / 3) * 8 + 4 + (row % 3)] = sum;
     }
+
+    // ---- spatial coherence (:40-74, :118-127): largest 8-connected component of every
+    // cluster, found on chip.  Each thread takes its pixels (cell in the box, cluster) into
+    // registers; the pixel store is then reused as a grid over the box: parent u16 + cluster u8.
+    constexpr int NPT = CAP / THREADS;
+    static_assert(NPT * THREADS == CAP, "CAP must be a multiple of the block size");
+    uint32_t keep[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int i = tid + t * THREADS;
+        keep[t] = i < n ? ((uint32_t)pos[i] | ((pix[i] >> 24) << 16)) : 0xffffffffu;
+    }
+    uint16_t* par = reinterpret_cast<uint16_t*>(smem);
+    uint8_t* cls = smem + (((size_t)area * 2 + 3) & ~(size_t)3);
+    uint32_t* largest = reinterpret_cast<uint32_t*>(slots);
+    __syncthreads();
+    for (int i = tid; i < (area + 3) / 4; i += THREADS) reinterpret_cast<uint32_t*>(cls)[i] = 0xffffffffu;
+    if (tid < KM) largest[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu) {
+            const uint32_t cell = keep[t] & 0xffffu;
+            cls[cell] = (uint8_t)(keep[t] >> 16);
+            par[cell] = (uint16_t)cell;
+        }
+    __syncthreads();
+    // links to the W / NW / N / NE neighbours of the same cluster; links implied by the
+    // neighbours' own links are skipped (N present: NW-N, N-NE and W-N exist already)
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu) {
+            const uint32_t cell = keep[t] & 0xffffu;
+            const uint8_t c = (uint8_t)(keep[t] >> 16);
+            int yy = (int)((float)cell * inv_bw);
+            int xx = (int)cell - yy * bw;
+            yy += (xx >= bw) - (xx < 0);
+            xx = (int)cell - yy * bw;
+            const bool up = yy > 0, lf = xx > 0, rt = xx < bw - 1;
+            if (up && cls[cell - bw] == c) {
+                unite16(par, cell, cell - bw);
+            } else {
+                if (lf && cls[cell - 1] == c)
+                    unite16(par, cell, cell - 1);
+                else if (up && lf && cls[cell - bw - 1] == c)
+                    unite16(par, cell, cell - bw - 1);
+                if (up && rt && cls[cell - bw + 1] == c) unite16(par, cell, cell - bw + 1);
+            }
+        }
+    __syncthreads();
+    // roots into registers (bit 24: this cell is a root), then the parent grid turns into
+    // 16-bit size counters (two per word; a segment has < 65536 pixels, so no carry)
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu) {
+            const uint32_t cell = keep[t] & 0xffffu;
+            const uint32_t root = find16(par, cell);
+            keep[t] = root | (keep[t] & 0xff0000u) | (root == cell ? 0x1000000u : 0u);
+        }
+    __syncthreads();
+    for (int i = tid; i < (area + 1) / 2; i += THREADS) reinterpret_cast<uint32_t*>(par)[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu) {
+            const uint32_t root = keep[t] & 0xffffu;
+            atomicAdd(reinterpret_cast<uint32_t*>(par) + (root >> 1), 1u << ((root & 1u) * 16u));
+        }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu && (keep[t] & 0x1000000u))
+            atomicMax(&largest[(keep[t] >> 16) & 0xffu], (uint32_t)par[keep[t] & 0xffffu]);
+    __syncthreads();
+    SEG_MARK(8)
     if (tid < k) {
         out[tid * 8] = red[tid * 4];
         out[tid * 8 + 1] = red[tid * 4 + 1];
         out[tid * 8 + 2] = red[tid * 4 + 2];
         out[tid * 8 + 3] = red[tid * 4 + 3];
-        out[tid * 8 + 7] = 0ull;                        // largest component: filled by the CC stage
+        out[tid * 8 + 7] = largest[tid];
         float* dst = centres + (gs * k + tid) * 3;
-        dst[0] = cen[tid * 3];
-        dst[1] = cen[tid * 3 + 1];
-        dst[2] = cen[tid * 3 + 2];
+        dst[0] = cen[tid];
+        dst[1] = cen[KM + tid];
+        dst[2] = cen[2 * KM + tid];
     }
     if (tid == 0) {
         st.rounds = s_done;
@@ -315,15 +575,42 @@ __global__ __launch_bounds__(SEG_THREADS) void dcd_segment_kernel(
     }
 }
 
-size_t seg_lds_bytes(int km) {
-    return (size_t)SEG_CAP * 6 + (size_t)km * 3 * 64 * 4 + (size_t)km * 8 + (size_t)km * 3 * 4 * 2 +
+size_t seg_lds_bytes(int km, int cap) {
+    const int accw = (cap / 64) * 255 < 65536 ? 3 : 4;
+    return (size_t)cap * 6 + (size_t)km * accw * 64 * 4 + (size_t)km * 8 + (size_t)km * 3 * 4 * 2 +
            (size_t)km * 4 * 4 + 16;
+}
+
+template <int KM, int CAP, int THREADS, bool FIRST>
+int launch_tier(dim3 grid, hipStream_t st, const uint8_t* lab, const int32_t* labels, int H, int W,
+                int nseg, int k, int use_hash, uint32_t seed, float* centres, uint8_t* assign,
+                SegState* seg, unsigned long long* stats, const int* bbox, int* n_big,
+                int max_rounds) {
+    size_t lds = seg_lds_bytes(KM, CAP);
+    auto fn = dcd_segment_kernel<KM, CAP, THREADS, FIRST>;
+    IMGAN_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    hipLaunchKernelGGL(fn, grid, dim3(THREADS), lds, st, lab, labels, H, W, nseg, k, use_hash, seed,
+                       centres, assign, seg, stats, bbox, n_big, max_rounds);
+    return 0;
 }
 
 }  // namespace
 
+#ifdef IMGAN_SEG_TIMING
+extern "C" int imgan_debug_seg_timing(unsigned long long* out16, int reset) {
+    IMGAN_HIP(hipDeviceSynchronize());
+    IMGAN_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(seg_timing), 128));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        IMGAN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(seg_timing), z, 128));
+    }
+    return 0;
+}
+#endif
+
 extern "C" size_t imgan_dcd_bbox_bytes(int B, int nseg) {
-    return (B < 1 || nseg < 1) ? 0 : imgan::align_up((size_t)B * nseg * 5 * 4 + 16, 256);
+    return (B < 1 || nseg < 1) ? 0 : imgan::align_up((size_t)B * nseg * 4 * 4 + 16, 256);
 }
 
 extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
@@ -348,23 +635,22 @@ extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int
     IMGAN_HIP(hipMemsetAsync(assign, 0xff, (size_t)B * H * W, st));
     hipLaunchKernelGGL(seg_bbox_init_kernel, dim3((unsigned)imgan::cdiv((long long)nsegs, 256)),
                        dim3(256), 0, st, bbox, (int)nsegs);
-    dim3 gb((unsigned)imgan::cdiv(W, 256), (unsigned)H, (unsigned)B);
+    dim3 gb((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, BBOX_ROWS), (unsigned)B);
     hipLaunchKernelGGL(seg_bbox_kernel, gb, dim3(256), 0, st, labels, H, W, nseg, bbox);
     dim3 gs((unsigned)nseg, (unsigned)B);
+    unsigned long long* stt = (unsigned long long*)stats;
+#define TIER(KM, CAP, THR, FIRST)                                                                  \
+    if (int rc = launch_tier<KM, CAP, THR, FIRST>(gs, st, lab, labels, H, W, nseg, k, use_hash_init, \
+                                                  seed, centres, assign, seg, stt, bbox, n_big_out,  \
+                                                  max_rounds))                                       \
+        return rc;
     if (k <= 8) {
-        size_t lds = seg_lds_bytes(8);
-        IMGAN_HIP(hipFuncSetAttribute((const void*)dcd_segment_kernel<8>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((dcd_segment_kernel<8>), gs, dim3(SEG_THREADS), lds, st, lab, labels, H,
-                           W, nseg, k, use_hash_init, seed, centres, assign, seg,
-                           (unsigned long long*)stats, (const int*)bbox, n_big_out, max_rounds);
+        TIER(8, CAP_SMALL, THREADS_SMALL, true)
+        TIER(8, CAP_LARGE, THREADS_LARGE, false)
     } else {
-        size_t lds = seg_lds_bytes(16);
-        IMGAN_HIP(hipFuncSetAttribute((const void*)dcd_segment_kernel<16>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((dcd_segment_kernel<16>), gs, dim3(SEG_THREADS), lds, st, lab, labels, H,
-                           W, nseg, k, use_hash_init, seed, centres, assign, seg,
-                           (unsigned long long*)stats, (const int*)bbox, n_big_out, max_rounds);
+        TIER(16, CAP_SMALL, THREADS_SMALL, true)
+        TIER(16, CAP_LARGE, THREADS_LARGE, false)
     }
+#undef TIER
     return imgan::check_launch("imgan_dcd_segments");
 }

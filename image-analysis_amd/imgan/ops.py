@@ -274,8 +274,10 @@ def cc_label(values):
 class DcdPlan(object):
     """Dominant colours of every segment of a label map (mpeg7Descriptors.py:76-130).
 
-    Segments that fit on chip are finished by the LDS-resident kernel in one launch; larger
-    ones (merged regions) continue through the streaming rounds.  Both give the same numbers."""
+    Segments that fit on chip are finished by the LDS-resident kernel in one launch (Lloyd
+    rounds, statistics and the connected components behind the coherence value); larger ones
+    (merged regions) continue through the streaming rounds and the whole-image component
+    labelling.  Both give the same numbers."""
 
     def __init__(self, B, H, W, nseg, k):
         _require_gpu()
@@ -354,6 +356,8 @@ class DcdPlan(object):
         lab = as_batch(_dev(lab, torch.uint8, "lab"))
         if labels.dim() == 2:
             labels = labels.unsqueeze(0)
+        if not streaming_only and self.big_segments == 0:
+            return self.stats            # every segment was finished on chip, coherence included
         if self.scratch is None:
             self.scratch = torch.empty((3, self.B, self.H, self.W), dtype=torch.int32,
                                        device=self.state.device)
