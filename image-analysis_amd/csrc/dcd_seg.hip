@@ -47,13 +47,25 @@ static_assert((CAP_SMALL / 64) * 255 < 65536, "packed accumulators would overflo
 
 // bbox: int [nsegs][4] = xmin, ymin, xmax, ymax.  One block = 256 columns x BBOX_ROWS rows
 // (a block per row was bound by the workgroup dispatch rate, not by memory).  Each wave walks
-// down its 64 columns; per row the extremes of every label run come from a ballot, and an
-// atomic is only issued when it can still move the stored extreme (the pre-read may be stale,
-// which only costs a redundant atomic).
-constexpr int BBOX_ROWS = 32;
+// down its 64 columns; per row the extremes of every label run come from a ballot and go into
+// a small LDS table keyed by label (fire-and-forget LDS atomics: nothing waits on global
+// memory in the loop); the table is flushed with one global atomic per entry and field.
+constexpr int BBOX_ROWS = 32, BBOX_SLOTS = 128;
+
+struct BboxTable {
+    int key[BBOX_SLOTS];
+    int ext[BBOX_SLOTS][4];
+};
+
+__device__ __forceinline__ void bbox_global(int* __restrict__ bb, int xa, int ya, int xb, int yb) {
+    atomicMin(&bb[0], xa);
+    atomicMin(&bb[1], ya);
+    atomicMax(&bb[2], xb);
+    atomicMax(&bb[3], yb);
+}
 
 __device__ __forceinline__ void bbox_row(int pending, int x, int y, int lane, int nseg, int b,
-                                         int* __restrict__ bbox) {
+                                         BboxTable& T, int* __restrict__ bbox) {
     while (true) {
         unsigned long long act = __ballot(pending >= 0);
         if (act == 0ull) break;
@@ -64,12 +76,25 @@ __device__ __forceinline__ void bbox_row(int pending, int x, int y, int lane, in
         // lanes are consecutive columns of one row: the extremes are the first / last set bit
         int first = __ffsll((long long)who) - 1, last = 63 - __clzll((long long)who);
         if (lane == leader) {
-            int* bb = bbox + ((size_t)b * nseg + cur) * 4;
-            int xb = x - lane;
-            if (xb + first < bb[0]) atomicMin(&bb[0], xb + first);
-            if (y < bb[1]) atomicMin(&bb[1], y);
-            if (xb + last > bb[2]) atomicMax(&bb[2], xb + last);
-            if (y > bb[3]) atomicMax(&bb[3], y);
+            const int xa = x - lane + first, xb = x - lane + last;
+            int idx = (int)(((uint32_t)cur * 0x9e3779b1u) >> 25);
+            bool placed = false;
+            for (int probe = 0; probe < BBOX_SLOTS; ++probe) {
+                const int old = atomicCAS(&T.key[idx], -1, cur);
+                if (old == -1 || old == cur) {
+                    placed = true;
+                    break;
+                }
+                idx = (idx + 1) & (BBOX_SLOTS - 1);
+            }
+            if (placed) {
+                atomicMin(&T.ext[idx][0], xa);
+                atomicMin(&T.ext[idx][1], y);
+                atomicMax(&T.ext[idx][2], xb);
+                atomicMax(&T.ext[idx][3], y);
+            } else {                                    // more labels than slots in this block
+                bbox_global(bbox + ((size_t)b * nseg + cur) * 4, xa, y, xb, y);
+            }
         }
         if (mine) pending = -1;
     }
@@ -77,11 +102,18 @@ __device__ __forceinline__ void bbox_row(int pending, int x, int y, int lane, in
 
 __global__ __launch_bounds__(256) void seg_bbox_kernel(const int32_t* __restrict__ labels, int H,
                                                        int W, int nseg, int* __restrict__ bbox) {
+    __shared__ BboxTable T;
     const int b = blockIdx.z;
     const int y0 = blockIdx.y * BBOX_ROWS;
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int xc = x < W ? x : W - 1;
+    if (threadIdx.x < BBOX_SLOTS) {
+        T.key[threadIdx.x] = -1;
+        T.ext[threadIdx.x][0] = T.ext[threadIdx.x][1] = 0x7fffffff;
+        T.ext[threadIdx.x][2] = T.ext[threadIdx.x][3] = -1;
+    }
+    __syncthreads();
     const int32_t* col = labels + (size_t)b * H * W + xc;
     for (int r = 0; r < BBOX_ROWS; r += 4) {
         int l[4];
@@ -94,9 +126,13 @@ __global__ __launch_bounds__(256) void seg_bbox_kernel(const int32_t* __restrict
         for (int u = 0; u < 4; ++u) {
             int y = y0 + r + u;
             bool ok = x < W && y < H && l[u] >= 0 && l[u] < nseg;
-            bbox_row(ok ? l[u] : -1, x, y, lane, nseg, b, bbox);
+            bbox_row(ok ? l[u] : -1, x, y, lane, nseg, b, T, bbox);
         }
     }
+    __syncthreads();
+    if (threadIdx.x < BBOX_SLOTS && T.key[threadIdx.x] >= 0)
+        bbox_global(bbox + ((size_t)b * nseg + T.key[threadIdx.x]) * 4, T.ext[threadIdx.x][0],
+                    T.ext[threadIdx.x][1], T.ext[threadIdx.x][2], T.ext[threadIdx.x][3]);
 }
 
 __global__ void seg_bbox_init_kernel(int* __restrict__ bbox, int nsegs) {

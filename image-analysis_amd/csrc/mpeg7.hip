@@ -5,9 +5,9 @@
 // 8x8 DCT, in double with a fixed operation order (build uses -ffp-contract=off).
 //
 // All three are one streaming pass over the BGR image (3 B/px; CSD only touches the
-// sub-sampled grid).  Sums are aggregated per wave (a run of 64 pixels of one row falls into
-// very few blocks / quadrants) before any atomic is issued; CSD builds its 256-bin histogram
-// in LDS (privatised per workgroup) and flushes once.
+// sub-sampled grid).  The CLD / EHD sums walk row strips with the column-dependent indices
+// fixed per thread and the sums in registers; CSD builds its 256-bin histogram in LDS
+// (privatised per workgroup) and flushes once.
 #include "common.h"
 #include "../../include/imgan.h"
 #include <math.h>
@@ -30,45 +30,98 @@ __device__ __forceinline__ uint32_t gray_px(uint32_t b, uint32_t g, uint32_t r) 
     return (4899u * r + 9617u * g + 1868u * b + 8192u) >> 14;
 }
 
-// ------------------------------------------------------------------------------ CLD
-// sums: u64 [B][64][4] = B, G, R sums and pixel count of the 8x8 grid blocks
-__global__ __launch_bounds__(256) void cld_sums_kernel(const uint8_t* __restrict__ img, int H,
-                                                       int W, unsigned long long* __restrict__ sums) {
-    const int b = blockIdx.y;
-    const long long npix = (long long)H * W;
-    const uint8_t* im = img + (size_t)b * npix * 3;
-    unsigned long long* S = sums + (size_t)b * 64 * 4;
-    const long long chunk = (long long)blockIdx.x * (256 * 8);
-    for (int it = 0; it < 8; ++it) {
-        long long p = chunk + (long long)it * 256 + threadIdx.x;
-        int pending = -1;
-        uint32_t c0 = 0, c1 = 0, c2 = 0;
-        if (p < npix) {
-            int y = (int)(p / W), x = (int)(p - (long long)y * W);
-            pending = ((y * 8) / H) * 8 + (x * 8) / W;
-            const uint8_t* q = im + p * 3;
-            c0 = q[0];
-            c1 = q[1];
-            c2 = q[2];
-        }
-        while (true) {
-            unsigned long long act = __ballot(pending >= 0);
-            if (act == 0ull) break;
-            int leader = __ffsll((long long)act) - 1;
-            int cur = __shfl(pending, leader);
-            bool mine = (pending == cur);
-            uint32_t w0 = wave_sum(mine ? (c0 | (c1 << 16)) : 0u);
-            uint32_t w1 = wave_sum(mine ? (c2 | (1u << 16)) : 0u);
-            if ((int)(threadIdx.x & 63) == leader) {
-                unsigned long long* s = S + (size_t)cur * 4;
-                atomicAdd(&s[0], (unsigned long long)(w0 & 0xffffu));
-                atomicAdd(&s[1], (unsigned long long)(w0 >> 16));
-                atomicAdd(&s[2], (unsigned long long)(w1 & 0xffffu));
-                atomicAdd(&s[3], (unsigned long long)(w1 >> 16));
-            }
-            if (mine) pending = -1;
+// ---- row-strip helpers shared by the CLD and EHD sums.  A thread owns 4 adjacent pixel
+// columns and walks down a strip of rows, so everything that depends on the column (grid
+// block, sub-block quadrant) is fixed per thread and the sums stay in registers until the
+// strip ends.  Four rows are requested before the first is used; rows past the strip are
+// clamped and masked instead of branched around.
+struct __attribute__((packed, aligned(4))) Bgr4 {
+    uint32_t a, b, c;
+};
+
+// px[j] = B | G << 8 | R << 16 of pixel x + j (0 outside the image)
+template <bool ALIGNED>
+__device__ __forceinline__ void load_quad(const uint8_t* __restrict__ row, int x, int W,
+                                          uint32_t mask, uint32_t* px) {
+    if (ALIGNED) {                                   // W % 4 == 0: 12 aligned bytes
+        const Bgr4 v = *reinterpret_cast<const Bgr4*>(row + (size_t)x * 3);
+        px[0] = v.a & 0xffffffu & mask;
+        px[1] = __builtin_amdgcn_perm(v.b, v.a, 0x0c050403u) & mask;
+        px[2] = __builtin_amdgcn_perm(v.c, v.b, 0x0c040302u) & mask;
+        px[3] = (v.c >> 8) & mask;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = x + j < W ? x + j : W - 1;
+            const uint8_t* q = row + (size_t)xx * 3;
+            const uint32_t v = q[0] | (q[1] << 8) | (q[2] << 16);
+            px[j] = x + j < W ? (v & mask) : 0u;
         }
     }
+}
+
+// ------------------------------------------------------------------------------ CLD
+// sums: u64 [B][64][4] = B, G, R sums and pixel count of the 8x8 grid blocks (zeroed by the
+// host wrapper).  Grid row gy owns the image rows with (y * 8) / H == gy; one workgroup takes
+// a quarter of such a band at full width.
+constexpr int CLD_PARTS = 4;
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void cld_sums_kernel(const uint8_t* __restrict__ img, int H,
+                                                       int W, unsigned long long* __restrict__ sums) {
+    __shared__ unsigned long long tab[8][4];
+    const int b = blockIdx.z, gy = blockIdx.y / CLD_PARTS, part = blockIdx.y % CLD_PARTS;
+    const int r0 = (gy * H + 7) / 8, r1 = ((gy + 1) * H + 7) / 8;
+    const int per = (r1 - r0 + CLD_PARTS - 1) / CLD_PARTS;
+    const int ya = r0 + part * per, yb = min(ya + per, r1);
+    const int tid = threadIdx.x;
+    if (tid < 32) tab[tid >> 2][tid & 3] = 0ull;
+    __syncthreads();
+    const uint8_t* im = img + (size_t)b * H * W * 3;
+    const int nquad = (W + 3) / 4;
+    for (int q0 = 0; q0 < nquad && ya < yb; q0 += 256) {
+        const int x = (q0 + tid) * 4;
+        const bool live = x < W;
+        const int xl = live ? x : 0;
+        uint32_t e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};     // B | R << 16 and G
+        int nrows = 0;
+        auto flush = [&]() {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (live && x + j < W) {
+                    const int gx = ((x + j) * 8) / W;
+                    atomicAdd(&tab[gx][0], (unsigned long long)(e[j] & 0xffffu));
+                    atomicAdd(&tab[gx][1], (unsigned long long)o[j]);
+                    atomicAdd(&tab[gx][2], (unsigned long long)(e[j] >> 16));
+                    atomicAdd(&tab[gx][3], (unsigned long long)nrows);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = o[j] = 0;
+            nrows = 0;
+        };
+        for (int y = ya; y < yb; y += 4) {
+            uint32_t px[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int yy = y + u < yb ? y + u : yb - 1;
+                load_quad<ALIGNED>(im + (size_t)yy * W * 3, xl, W, y + u < yb ? 0xffffffffu : 0u,
+                                   px[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    e[j] += px[u][j] & 0xff00ffu;
+                    o[j] += (px[u][j] >> 8) & 0xffu;
+                }
+            nrows += min(4, yb - y);
+            if (nrows >= 252) flush();                 // the 16-bit halves of e hold 257 rows
+        }
+        flush();
+    }
+    __syncthreads();
+    if (tid < 32 && tab[tid >> 2][tid & 3])
+        atomicAdd(&sums[((size_t)b * 64 + gy * 8 + (tid >> 2)) * 4 + (tid & 3)], tab[tid >> 2][tid & 3]);
 }
 
 struct DctTable {
@@ -152,41 +205,53 @@ __global__ void cld_finalise_kernel(const unsigned long long* __restrict__ sums,
 }
 
 // ------------------------------------------------------------------------------ EHD
-// qsum: u32 [B][nby*nbx][4] quadrant gray sums (zero-filled by the host wrapper)
+// qsum: u32 [B][nby*nbx][4] quadrant gray sums.  One workgroup owns one row of quadrants
+// (sub-block row by, upper or lower half) at full width, so it writes its sums with plain
+// stores.  tab: dynamic LDS, nbx * 2 words.
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void ehd_sums_kernel(const uint8_t* __restrict__ img, int H,
                                                        int W, int bs, int nbx, int nby,
                                                        uint32_t* __restrict__ qsum) {
-    const int b = blockIdx.y;
-    const long long npix = (long long)H * W;
-    const uint8_t* im = img + (size_t)b * npix * 3;
-    uint32_t* Q = qsum + (size_t)b * nbx * nby * 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t ehd_tab[];
+    const int b = blockIdx.y, by = blockIdx.x >> 1, qy = blockIdx.x & 1;
     const int hb = bs >> 1;
-    const long long chunk = (long long)blockIdx.x * (256 * 8);
-    for (int it = 0; it < 8; ++it) {
-        long long p = chunk + (long long)it * 256 + threadIdx.x;
-        int pending = -1;
-        uint32_t g = 0;
-        if (p < npix) {
-            int y = (int)(p / W), x = (int)(p - (long long)y * W);
-            int bx = x / bs, by = y / bs;
-            if (bx < nbx && by < nby) {
-                int qx = (x - bx * bs) >= hb, qy = (y - by * bs) >= hb;
-                pending = (by * nbx + bx) * 4 + qy * 2 + qx;
-                const uint8_t* q = im + p * 3;
-                g = gray_px(q[0], q[1], q[2]);
+    const int ya = by * bs + qy * hb, yb = ya + hb;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nbx * 2; i += 256) ehd_tab[i] = 0;
+    __syncthreads();
+    const uint8_t* im = img + (size_t)b * H * W * 3;
+    const int wuse = nbx * bs;                          // columns right of it belong to no block
+    const int nquad = (wuse + 3) / 4;
+    for (int q0 = 0; q0 < nquad; q0 += 256) {
+        const int x = (q0 + tid) * 4;
+        const bool live = x < wuse;
+        const int xl = live ? x : 0;
+        uint32_t g[4] = {0, 0, 0, 0};
+        for (int y = ya; y < yb; y += 4) {
+            uint32_t px[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int yy = y + u < yb ? y + u : yb - 1;
+                load_quad<ALIGNED>(im + (size_t)yy * W * 3, xl, W, y + u < yb ? 0xffffffffu : 0u,
+                                   px[u]);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)            // a masked pixel has gray 0
+                    g[j] += gray_px(px[u][j] & 0xffu, (px[u][j] >> 8) & 0xffu, px[u][j] >> 16);
         }
-        while (true) {
-            unsigned long long act = __ballot(pending >= 0);
-            if (act == 0ull) break;
-            int leader = __ffsll((long long)act) - 1;
-            int cur = __shfl(pending, leader);
-            bool mine = (pending == cur);
-            uint32_t s = wave_sum(mine ? g : 0u);
-            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&Q[cur], s);
-            if (mine) pending = -1;
-        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (live && x + j < wuse) {
+                const int bx = (x + j) / bs;
+                const int qx = (x + j - bx * bs) >= hb;
+                atomicAdd(&ehd_tab[bx * 2 + qx], g[j]);
+            }
     }
+    __syncthreads();
+    uint32_t* Q = qsum + ((size_t)b * nby + by) * nbx * 4;
+    for (int i = tid; i < nbx * 2; i += 256) Q[(i >> 1) * 4 + qy * 2 + (i & 1)] = ehd_tab[i];
 }
 
 __global__ void ehd_classify_kernel(const uint32_t* __restrict__ qsum, int B, int H, int W, int bs,
@@ -354,10 +419,13 @@ extern "C" int imgan_cld(const uint8_t* bgr, int B, int H, int W, int32_t* cld_o
     IMGAN_REQUIRE((long long)H * 8 < 0x7fffffffLL && (long long)W * 8 < 0x7fffffffLL, "imgan_cld: too large");
     hipStream_t st = (hipStream_t)stream;
     IMGAN_HIP(hipMemsetAsync(scratch, 0, imgan_cld_scratch_bytes(B), st));
-    long long npix = (long long)H * W;
-    dim3 grid((unsigned)imgan::cdiv(npix, 256 * 8), (unsigned)B);
-    hipLaunchKernelGGL(cld_sums_kernel, grid, dim3(256), 0, st, bgr, H, W,
-                       (unsigned long long*)scratch);
+    dim3 grid(1, 8 * CLD_PARTS, (unsigned)B);
+    if (W % 4 == 0 && ((uintptr_t)bgr & 3) == 0)
+        hipLaunchKernelGGL(cld_sums_kernel<true>, grid, dim3(256), 0, st, bgr, H, W,
+                           (unsigned long long*)scratch);
+    else
+        hipLaunchKernelGGL(cld_sums_kernel<false>, grid, dim3(256), 0, st, bgr, H, W,
+                           (unsigned long long*)scratch);
     DctTable T;
     for (int i = 0; i < 8; ++i) {
         double s = i == 0 ? sqrt(0.125) : 0.5;
@@ -392,11 +460,20 @@ extern "C" int imgan_ehd(const uint8_t* bgr, int B, int H, int W, int32_t* ehd_o
     IMGAN_REQUIRE((double)(bs / 2) * (bs / 2) * 255.0 < 4294967295.0, "imgan_ehd: image too large");
     IMGAN_HIP(hipMemsetAsync(ehd_out, 0, (size_t)B * 96 * 4, st));
     if (nbx == 0 || nby == 0) return 0;
-    IMGAN_HIP(hipMemsetAsync(scratch, 0, imgan_ehd_scratch_bytes(B, H, W), st));
-    long long npix = (long long)H * W;
-    dim3 grid((unsigned)imgan::cdiv(npix, 256 * 8), (unsigned)B);
-    hipLaunchKernelGGL(ehd_sums_kernel, grid, dim3(256), 0, st, bgr, H, W, bs, nbx, nby,
-                       (uint32_t*)scratch);
+    const size_t lds = (size_t)nbx * 2 * 4;
+    IMGAN_REQUIRE(lds <= 160 * 1024 - 1024, "imgan_ehd: image too wide for the quadrant table");
+    dim3 grid((unsigned)nby * 2, (unsigned)B);
+    if (W % 4 == 0 && ((uintptr_t)bgr & 3) == 0) {
+        auto fn = ehd_sums_kernel<true>;
+        if (lds > 48 * 1024)
+            IMGAN_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, bgr, H, W, bs, nbx, nby, (uint32_t*)scratch);
+    } else {
+        auto fn = ehd_sums_kernel<false>;
+        if (lds > 48 * 1024)
+            IMGAN_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fn, grid, dim3(256), lds, st, bgr, H, W, bs, nbx, nby, (uint32_t*)scratch);
+    }
     int total = B * nbx * nby;
     hipLaunchKernelGGL(ehd_classify_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st,
                        (const uint32_t*)scratch, B, H, W, bs, nbx, nby, 11, ehd_out);
