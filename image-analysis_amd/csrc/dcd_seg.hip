@@ -147,11 +147,17 @@ __global__ void seg_bbox_init_kernel(int* __restrict__ bbox, int nsegs) {
 
 // ---- union-find on 16-bit parents in LDS (the hardware has no 16-bit LDS atomics: a
 // compare-and-swap on the containing word stands in for atomicMin)
-__device__ __forceinline__ uint32_t find16(const volatile uint16_t* par, uint32_t a) {
+// find with path halving.  The halving store may race with a concurrent atomic_min16 on the
+// same entry; either value is an ancestor of the cell, so no link is lost (the uniting thread
+// carries on with the value it displaced).
+__device__ __forceinline__ uint32_t find16(volatile uint16_t* par, uint32_t a) {
     while (true) {
-        uint32_t p = par[a];
+        const uint32_t p = par[a];
         if (p == a) return a;
-        a = p;
+        const uint32_t g = par[p];
+        if (g == p) return p;
+        par[a] = (uint16_t)g;
+        a = g;
     }
 }
 
@@ -344,11 +350,12 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
     int rounds = 0;
     const float NEAR = 1.0f - 9.5367431640625e-07f;       // 1 - 2^-20
 
-    // ---- Lloyd rounds (:85-107)
+    // ---- Lloyd rounds (:85-107).  Two barriers per round: all waves assign, then the first
+    // wave alone folds the lane-private sums (clearing them for the next round), moves the
+    // centres and applies the stop rule while the CU's other workgroup keeps the SIMDs busy.
+    for (int i = tid; i < k * WORDS * 64; i += THREADS) acc[i] = 0;
+    __syncthreads();
     while (true) {
-        for (int i = tid; i < k * WORDS * 64; i += THREADS) acc[i] = 0;
-        __syncthreads();
-        SEG_MARK(6)
         // centres in registers, two per packed fp32 operand (v_pk_add/mul_f32: IEEE per half)
         f32x2 c0[KM / 2], c1[KM / 2], c2[KM / 2];
 #pragma unroll
@@ -406,37 +413,41 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
         }
         __syncthreads();
         SEG_MARK(2)
-        // reduce the 64 lane-private copies: 4 lanes per (cluster, word) row, 16 copies each
-        if (tid < k * WORDS * 4) {
-            const int row = tid >> 2, q = tid & 3;
-            uint32_t lo = 0, hi = 0;
-            const uint4* src = reinterpret_cast<const uint4*>(acc + row * 64 + q * 16);
+        if (wave == 0) {
+            // reduce the 64 lane-private copies: 4 lanes per (cluster, word) row, 16 copies each
+            for (int row0 = 0; row0 < k * WORDS; row0 += 16) {
+                const int row = row0 + (lane >> 2), q = lane & 3;
+                uint32_t lo = 0, hi = 0;
+                if (row < k * WORDS) {
+                    uint4* src = reinterpret_cast<uint4*>(acc + row * 64 + q * 16);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                uint4 w4 = src[t];
-                if (PACKED) {
-                    lo += (w4.x & 0xffffu) + (w4.y & 0xffffu) + (w4.z & 0xffffu) + (w4.w & 0xffffu);
-                    hi += (w4.x >> 16) + (w4.y >> 16) + (w4.z >> 16) + (w4.w >> 16);
-                } else {
-                    lo += w4.x + w4.y + w4.z + w4.w;
+                    for (int t = 0; t < 4; ++t) {
+                        const uint4 w4 = src[t];
+                        src[t] = make_uint4(0, 0, 0, 0);
+                        if (PACKED) {
+                            lo += (w4.x & 0xffffu) + (w4.y & 0xffffu) + (w4.z & 0xffffu) + (w4.w & 0xffffu);
+                            hi += (w4.x >> 16) + (w4.y >> 16) + (w4.z >> 16) + (w4.w >> 16);
+                        } else {
+                            lo += w4.x + w4.y + w4.z + w4.w;
+                        }
+                    }
+                }
+                lo += __shfl_xor(lo, 1);
+                hi += __shfl_xor(hi, 1);
+                lo += __shfl_xor(lo, 2);
+                hi += __shfl_xor(hi, 2);
+                if (q == 0 && row < k * WORDS) {
+                    if (PACKED) {           // row = cluster*2 + word: {count, s0}, {s1, s2}
+                        red[row * 2] = lo;
+                        red[row * 2 + 1] = hi;
+                    } else {                // row = cluster*4 + {count, s0, s1, s2}
+                        red[row] = lo;
+                    }
                 }
             }
-            lo += __shfl_xor(lo, 1);
-            hi += __shfl_xor(hi, 1);
-            lo += __shfl_xor(lo, 2);
-            hi += __shfl_xor(hi, 2);
-            if (q == 0) {
-                if (PACKED) {               // row = cluster*2 + word: {count, s0}, {s1, s2}
-                    red[row * 2] = lo;
-                    red[row * 2 + 1] = hi;
-                } else {                    // row = cluster*4 + {count, s0, s1, s2}
-                    red[row] = lo;
-                }
-            }
-        }
-        __syncthreads();
-        SEG_MARK(3)
-        if (wave == 0) {                    // centre update + stop rule (:93-107)
+            __threadfence_block();          // red is read back by other lanes of this wave
+            SEG_MARK(3)
+            // centre update + stop rule (:93-107)
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
             if (lane < k) {
                 const uint32_t nj = red[lane * 4];
@@ -535,19 +546,21 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
     uint8_t* cls = smem + (((size_t)area * 2 + 3) & ~(size_t)3);
     uint32_t* largest = reinterpret_cast<uint32_t*>(slots);
     __syncthreads();
+    SEG_MARK(9)
     for (int i = tid; i < (area + 3) / 4; i += THREADS) reinterpret_cast<uint32_t*>(cls)[i] = 0xffffffffu;
     if (tid < KM) largest[tid] = 0;
     __syncthreads();
+    SEG_MARK(10)
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
-        if (keep[t] != 0xffffffffu) {
-            const uint32_t cell = keep[t] & 0xffffu;
-            cls[cell] = (uint8_t)(keep[t] >> 16);
-            par[cell] = (uint16_t)cell;
-        }
+        if (keep[t] != 0xffffffffu) cls[keep[t] & 0xffffu] = (uint8_t)(keep[t] >> 16);
     __syncthreads();
-    // links to the W / NW / N / NE neighbours of the same cluster; links implied by the
-    // neighbours' own links are skipped (N present: NW-N, N-NE and W-N exist already)
+    SEG_MARK(11)
+    // Every cell hangs itself under one earlier neighbour of its cluster (N, else W, else NW,
+    // else NE; all have a smaller index, so the links form a forest) with a plain store.
+    // Of the four backward links W / NW / N / NE only one more can be needed: with N present
+    // the others follow from the neighbours' own links (NW-N, N-NE, W-N), and W covers NW;
+    // what is left is NE next to a missing N, which is united explicitly below (bit 25).
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
         if (keep[t] != 0xffffffffu) {
@@ -558,17 +571,24 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
             yy += (xx >= bw) - (xx < 0);
             xx = (int)cell - yy * bw;
             const bool up = yy > 0, lf = xx > 0, rt = xx < bw - 1;
-            if (up && cls[cell - bw] == c) {
-                unite16(par, cell, cell - bw);
-            } else {
-                if (lf && cls[cell - 1] == c)
-                    unite16(par, cell, cell - 1);
-                else if (up && lf && cls[cell - bw - 1] == c)
-                    unite16(par, cell, cell - bw - 1);
-                if (up && rt && cls[cell - bw + 1] == c) unite16(par, cell, cell - bw + 1);
-            }
+            const bool n_ = up && cls[cell - bw] == c, w_ = lf && cls[cell - 1] == c;
+            const bool nw = up && lf && cls[cell - bw - 1] == c;
+            const bool ne = up && rt && cls[cell - bw + 1] == c;
+            const uint32_t link = n_ ? cell - bw : w_ ? cell - 1 : nw ? cell - bw - 1
+                                                  : ne ? cell - bw + 1 : cell;
+            par[cell] = (uint16_t)link;
+            if (!n_ && (w_ || nw) && ne) keep[t] |= 0x2000000u;
         }
     __syncthreads();
+    SEG_MARK(12)
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu && (keep[t] & 0x2000000u)) {
+            const uint32_t cell = keep[t] & 0xffffu;
+            unite16(par, cell, cell - bw + 1);
+        }
+    __syncthreads();
+    SEG_MARK(13)
     // roots into registers (bit 24: this cell is a root), then the parent grid turns into
     // 16-bit size counters (two per word; a segment has < 65536 pixels, so no carry)
 #pragma unroll
@@ -576,11 +596,14 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
         if (keep[t] != 0xffffffffu) {
             const uint32_t cell = keep[t] & 0xffffu;
             const uint32_t root = find16(par, cell);
+            par[cell] = (uint16_t)root;                 // shortens the walks of later cells
             keep[t] = root | (keep[t] & 0xff0000u) | (root == cell ? 0x1000000u : 0u);
         }
     __syncthreads();
+    SEG_MARK(14)
     for (int i = tid; i < (area + 1) / 2; i += THREADS) reinterpret_cast<uint32_t*>(par)[i] = 0;
     __syncthreads();
+    SEG_MARK(6)
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
         if (keep[t] != 0xffffffffu) {
@@ -588,6 +611,7 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
             atomicAdd(reinterpret_cast<uint32_t*>(par) + (root >> 1), 1u << ((root & 1u) * 16u));
         }
     __syncthreads();
+    SEG_MARK(15)
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
         if (keep[t] != 0xffffffffu && (keep[t] & 0x1000000u))

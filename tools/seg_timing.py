@@ -22,7 +22,7 @@ pipe.run_dcd()
 torch.cuda.synchronize()
 print('run_dcd %.2f ms' % ((time.time() - t0) * 1e3))
 lib.imgan_debug_seg_timing(buf, 1)
-names = ["startup", "gather-bar", "assign", "reduce", "update", "stats", "zero", "gather", "coherence"]
+names = ["startup", "gather-bar", "assign", "reduce", "update", "stats", "coh-zero", "gather", "coh-largest", "coh-keep", "coh-clear", "coh-scatter", "coh-link", "coh-unite", "coh-flatten", "coh-count"]
 tot = sum(buf)
 for n, v in zip(names, buf):
     print("%-8s %12d ticks  %5.1f%%" % (n, v, 100.0 * v / max(tot, 1)))
