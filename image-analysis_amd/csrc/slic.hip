@@ -253,7 +253,7 @@ struct __attribute__((packed, aligned(4))) Dword3 {
 };
 
 struct AssignParams {
-    int B, H, W, S, n, nsub, maxc, dbg;
+    int B, H, W, S, n, nsub, maxc;
     unsigned S2, cw2;         // integer key weights (modes 0, 1)
     double Sd, cw;            // literal float64 evaluation (mode 2 and exact-key ties)
 };
@@ -491,8 +491,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
                 uint32_t pp = __builtin_amdgcn_udot4(px[j], px[j], 0u, false);
                 T[j] = pp * P.S2 + P.cw2 * (uint32_t)((xr + j) * (xr + j) + yr * yr);
             }
-            const int mm = (P.dbg & 4) ? min(m, 1) : m;
-            for (int s = 0; s < mm; ++s) {
+            for (int s = 0; s < m; ++s) {
                 const int4 c0 = s_c0[s];
                 if (c0.y - S > wy0 + 3 || c0.y + S - 1 < wy0) continue;     // wave-level cull
                 const int2 bxy = *reinterpret_cast<const int2*>(&s_c1[s]);
@@ -567,8 +566,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
         bool all4 = true;
 #pragma unroll
         for (int j = 0; j < 4; ++j) all4 = all4 && valid[j] && slot[j] >= 0;
-        if (P.dbg & 2) {
-        } else if (ALIGNED && all4) {
+        if (ALIGNED && all4) {
             int4 o = make_int4(s_c1[slot[0]].z, s_c1[slot[1]].z, s_c1[slot[2]].z, s_c1[slot[3]].z);
             *reinterpret_cast<int4*>(labels + lbase) = o;
         } else {
@@ -578,7 +576,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (!valid[j] || (P.dbg & 1)) continue;
+            if (!valid[j]) continue;
             if (slot[j] >= 0) {
                 uint32_t p = px[j];
                 uint32_t* a = acc + slot[j] * 192 + lane;
@@ -744,8 +742,6 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
     double m_est = (double)(TW + 2 * S) * (TH * L.nsub + 2 * S) / ((double)S * S);
     P.maxc = std::min(MAXC, std::max(16, ((int)(2.0 * m_est) + 4 + 7) / 8 * 8));
     size_t lds_bytes = (size_t)P.maxc * (2 * sizeof(int4) + 3 * 64 * sizeof(uint32_t));
-    P.dbg = 0;
-    if (const char* e = getenv("IMGAN_SLIC_DEBUG")) P.dbg = atoi(e);
     dim3 grid((unsigned)L.ntx, (unsigned)L.nty, (unsigned)B);
     IMGAN_REQUIRE(grid.y <= 65535, "imgan_slic_assign_accumulate: image too tall");
     hipStream_t st = (hipStream_t)stream;
