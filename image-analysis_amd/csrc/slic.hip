@@ -33,7 +33,10 @@ constexpr int TH = 16;      // tile height (4 waves x 4 rows)
 constexpr int NSUBMAX = 4; // bands of 16 rows per tile (pixels of all bands prefetched)
 constexpr int MAXC = 48;    // most centres per tile the LDS fast path can be sized for
 constexpr int NFIELD = 6;   // sum L, a, b, x, y, count
-constexpr int TILE_REC = 1 + MAXC;   // int4 records per tile: header {m} + sorted candidates
+constexpr int TILE_REC = 1 + MAXC;   // 32-byte records per tile: header {m} + sorted candidates
+
+typedef int int8v __attribute__((ext_vector_type(8)));
+#define AS_CONST __attribute__((address_space(4)))   // loads through it are scalar loads
 
 struct Layout {
     int ncx, ncy, ncell;
@@ -67,7 +70,7 @@ Layout make_layout(int B, int H, int W, int S, int n) {
     L.nty = (H - 1 + TH * L.nsub - 1) / (TH * L.nsub);
     if (L.ntx < 1) L.ntx = 1;
     if (L.nty < 1) L.nty = 1;
-    L.off_tiles = take((size_t)B * L.ntx * L.nty * TILE_REC * 16);
+    L.off_tiles = take((size_t)B * L.ntx * L.nty * TILE_REC * sizeof(int8v));
     L.total = o;
     return L;
 }
@@ -79,7 +82,7 @@ struct Ws {
     int4* scand;            // cell-sorted copy of cand with .w = centre index
     int4* cand;             // cx, cy, packed Lab (L | a<<8 | b<<16), cell
     unsigned long long* sums;
-    int4* tiles;            // [B][nty][ntx][TILE_REC]: {m,..}, then {cx, cy, lab, idx} by idx
+    int8v* tiles;           // [B][nty][ntx][TILE_REC]: {m,..}, then the candidates by idx
     int ncx, ncy, ncell;
     int nsub, ntx, nty;
 };
@@ -96,7 +99,7 @@ Ws bind(void* ws, const Layout& L) {
     w.ncx = L.ncx;
     w.ncy = L.ncy;
     w.ncell = L.ncell;
-    w.tiles = (int4*)(p + L.off_tiles);
+    w.tiles = (int8v*)(p + L.off_tiles);
     w.nsub = L.nsub;
     w.ntx = L.ntx;
     w.nty = L.nty;
@@ -195,11 +198,23 @@ __global__ void slic_fill_kernel(Ws w, int B, int n) {
 }
 
 // ------------------------------------------------------------------ per-tile candidate lists
+struct AssignParams {
+    int B, H, W, S, n, nsub, maxc;
+    unsigned S2, cw2;         // integer key weights (modes 0, 1); cw2 = 0 in mode 2
+    double Sd, cw;            // literal float64 evaluation (mode 2 and exact-key ties)
+};
+
 // One wave per assignment tile: collects the centres whose window can reach the tile from the
-// cell lists, sorts them by centre index and writes a fixed-size record.  Doing this in its
-// own (tiny) launch takes two dependent memory round trips out of every assignment workgroup.
-__global__ __launch_bounds__(256) void slic_tiles_kernel(Ws w, int B, int H, int W, int S, int n) {
+// cell lists, sorts them by centre index and writes a fixed-size record of 8-dword entries
+//     {cx', cy', lab, idx, A, Bx, By, 0}       (cx', cy' relative to the tile origin)
+// with the per-candidate terms of the expanded integer key (see slic_assign_kernel):
+//     A = S^2 |c|^2 + cw^2 (cx'^2 + cy'^2),  Bx = 2 cw^2 cx',  By = 2 cw^2 cy'.
+// The assignment kernel reads the entries with scalar loads, so everything that is the same
+// for the whole wave (the entry itself, the row tests, the y part of the key) costs scalar
+// instructions only.
+__global__ __launch_bounds__(256) void slic_tiles_kernel(Ws w, AssignParams P) {
     __shared__ int4 u_c[4][MAXC];
+    const int B = P.B, H = P.H, W = P.W, S = P.S, n = P.n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntiles = w.ntx * w.nty;
     const long long t = (long long)blockIdx.x * 4 + wv;
@@ -237,25 +252,27 @@ __global__ __launch_bounds__(256) void slic_tiles_kernel(Ws w, int B, int H, int
     }
     __syncthreads();
     if (!live) return;
-    int4* rec = w.tiles + (size_t)t * TILE_REC;
-    if (lane == 0) rec[0] = make_int4(m, x0, y0, 0);
+    int8v* rec = w.tiles + (size_t)t * TILE_REC;
+    if (lane == 0) {
+        int8v h = {m, x0, y0, 0, 0, 0, 0, 0};
+        rec[0] = h;
+    }
     if (lane < m && m <= MAXC) {
         const int4 me = u_c[wv][lane];
         int rank = 0;
         for (int j = 0; j < m; ++j) rank += (u_c[wv][j].w < me.w);
-        rec[1 + rank] = me;
+        const int cxr = me.x - x0, cyr = me.y - y0;
+        const uint32_t cl = (uint32_t)me.z;
+        const uint32_t cc = __builtin_amdgcn_udot4(cl, cl, 0u, false);
+        const uint32_t A = P.S2 * cc + P.cw2 * (uint32_t)(cxr * cxr + cyr * cyr);
+        int8v e = {cxr, cyr, me.z, me.w, (int)A, 2 * (int)P.cw2 * cxr, 2 * (int)P.cw2 * cyr, 0};
+        rec[1 + rank] = e;
     }
 }
 
 // ------------------------------------------------------------------ assignment
 struct __attribute__((packed, aligned(4))) Dword3 {
     uint32_t a, b, c;
-};
-
-struct AssignParams {
-    int B, H, W, S, n, nsub, maxc;
-    unsigned S2, cw2;         // integer key weights (modes 0, 1)
-    double Sd, cw;            // literal float64 evaluation (mode 2 and exact-key ties)
 };
 
 // slic.py:101-109 evaluated literally in float64 (numpy order of operations, no contraction):
@@ -310,12 +327,22 @@ __device__ __forceinline__ void flush_pixel_global(unsigned long long* sums, int
     atomicAdd(&s[5], 1ull);
 }
 
-// MODE 0: u32 key with the dot4 expansion (fast path); 1: u64; 2: literal float64.
+// MODE 0: 32-bit key with the dot4 expansion (fast path); 1: u64; 2: literal float64.
+// REL (mode 0 only): the key is kept relative to its per-pixel constant (see below).
 //
-// One workgroup = a 64 x (16*nsub) pixel tile: the candidate list is gathered once and reused
-// for nsub bands of 16 rows (wave w takes rows 4w..4w+3 of each band, 16 lanes x 4 pixels per
-// row), so the latency of the gather (two dependent loads) and of the flush is amortised.
-template <int MODE, bool ALIGNED>
+// One workgroup = a 64 x (16*nsub) pixel tile; wave w takes rows 4w..4w+3 of every 16-row
+// band.  Inside a wave LANE = COLUMN and the four pixels of a lane are the four ROWS, so for a
+// given candidate everything that depends on the row is the same for all 64 lanes and lives
+// in scalar registers (the row-in-window tests, the y part of the key); per lane and
+// candidate only the column test and the x part are left.
+//
+// Mode 0 key.  With p, c the Lab bytes of pixel and centre, (x, y) / (cx', cy') tile relative:
+//     key = S^2 |p - c|^2 + cw^2 ((x - cx')^2 + (y - cy')^2)
+//         = T(p, x, y) + A(c) - Bx x - By y - 2 S^2 (p . c)
+// T is the same for every candidate of a pixel, so it cannot change which one wins: REL drops
+// it and compares the signed remainder (needs |key| < 2^31, checked on the host); otherwise
+// T is added and the comparison is unsigned below 2^32.  p . c is one v_dot4_u32_u8.
+template <int MODE, bool ALIGNED, bool REL>
 __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restrict__ lab,
                                                           int32_t* __restrict__ labels, Ws w,
                                                           AssignParams P) {
@@ -323,209 +350,204 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
     // (P.maxc): fewer bytes per workgroup = more workgroups per CU to hide the prologue.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int maxc = P.maxc;
-    int4* s_c0 = reinterpret_cast<int4*>(smem);          // by centre index: {cx', cy', lab, A}
-    int4* s_c1 = s_c0 + maxc;                            //                  {Bx, By, idx, 0}
-    uint32_t* acc = reinterpret_cast<uint32_t*>(s_c1 + maxc);   // [slot][word][lane] partial sums
+    int4* s_c = reinterpret_cast<int4*>(smem);                  // by rank: {cx', cy', lab, idx}
+    uint32_t* acc = reinterpret_cast<uint32_t*>(s_c + maxc);    // [slot][word][lane] partial sums
+    uint32_t* tr = acc + maxc * 192;                            // [wave][row][column] transposition
 
     const int b = blockIdx.z;
     const int H = P.H, W = P.W, S = P.S, n = P.n, nsub = P.nsub;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * (TH * nsub);
-    const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + TH * nsub - 1, H - 2);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    const int4* scand = w.scand + (size_t)b * n;
-    const int* start = w.start + (size_t)b * (w.ncell + 1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned long long* sums = w.sums + (size_t)b * n * NFIELD;
 
-    // centres that can cover a pixel of the tile: cx in [x0-S+1, x1+S], cy likewise
-    const int cxl = max(x0 - S + 1, 0) / S, cxh = min((x1 + S) / S, w.ncx - 1);
-    const int cyl = max(y0 - S + 1, 0) / S, cyh = min((y1 + S) / S, w.ncy - 1);
-
-    const int xr = (lane & 15) * 4;                      // tile relative column of pixel 0
-    const int x = x0 + xr;
-    const bool colok = x < W - 1;
-
-    // Every band's pixels are requested up front, before the candidate gather: the kernel is
-    // bound by bytes in flight, so each wave keeps nsub x 768 B outstanding instead of one
-    // row group at a time (measured: one group in flight ~1.3 TB/s for the bare skeleton).
+    // Every band's pixels are requested up front, before anything else: the kernel needs
+    // many bytes in flight, so each wave keeps nsub x 768 B outstanding.  The loads use the
+    // row-major mapping (16 lanes x 12 B per row, 4 rows); the bands are transposed to the
+    // lane = column mapping through LDS when they are used.
     auto unpack = [&](const Dword3& v, uint32_t* px) {
         px[0] = v.a & 0xffffffu;
         px[1] = __builtin_amdgcn_perm(v.b, v.a, 0x0c050403u);
         px[2] = __builtin_amdgcn_perm(v.c, v.b, 0x0c040302u);
         px[3] = v.c >> 8;
     };
-    auto load_px = [&](int yy, uint32_t* px) {           // generic (unaligned rows) loader
-        px[0] = px[1] = px[2] = px[3] = 0;
-        if (yy < H - 1 && colok) {
-            const uint8_t* src = lab + (((size_t)b * H + yy) * W + x) * 3;
-            if (ALIGNED) {
-                unpack(*reinterpret_cast<const Dword3*>(src), px);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (x + j < W) {
-                        const uint8_t* q = src + 3 * j;
-                        px[j] = q[0] | (q[1] << 8) | (q[2] << 16);
-                    }
-            }
-        }
-    };
     Dword3 raw[NSUBMAX];
     if (ALIGNED) {
+        const int xl = x0 + (lane & 15) * 4;
 #pragma unroll
         for (int sub = 0; sub < NSUBMAX; ++sub) {
             raw[sub].a = raw[sub].b = raw[sub].c = 0;
             const int yy = y0 + sub * TH + wave * 4 + (lane >> 4);
-            if (sub < nsub && yy < H - 1 && colok)
-                raw[sub] = *reinterpret_cast<const Dword3*>(lab + (((size_t)b * H + yy) * W + x) * 3);
+            if (sub < nsub && yy < H - 1 && xl < W - 1)
+                raw[sub] = *reinterpret_cast<const Dword3*>(lab + (((size_t)b * H + yy) * W + xl) * 3);
         }
     }
 
-    // the tile's sorted candidate record (slic_tiles_kernel): one round trip, every lane of
-    // the first wave fetches one entry whether it is used or not
-    const int4* rec = w.tiles + ((size_t)b * w.ntx * w.nty + (size_t)blockIdx.y * w.ntx + blockIdx.x) * TILE_REC;
-    const int m = rec[0].x;
-    int4 mine = make_int4(0, 0, 0, 0);
-    if (tid < MAXC) mine = rec[1 + tid];
+    // the tile's sorted candidate record (slic_tiles_kernel), read through the scalar cache
+    const size_t tile = (size_t)b * w.ntx * w.nty + (size_t)blockIdx.y * w.ntx + blockIdx.x;
+    const int8v* recv = w.tiles + tile * TILE_REC;
+    const int8v AS_CONST* rec = (const int8v AS_CONST*)recv;
+    const int m = rec[0][0];
+    if (tid < m && m <= maxc) {
+        const int8v e = recv[1 + tid];
+        s_c[tid] = make_int4(e[0], e[1], e[2], e[3]);
+    }
     for (int i = tid; i < maxc * 3 * 16; i += 256)
         reinterpret_cast<uint4*>(acc)[i] = make_uint4(0, 0, 0, 0);
 
+    const int xr = lane;                                 // tile relative column of this lane
+    const int x = x0 + xr;
+    const bool colok = x < W - 1;
+
     if (m > maxc) {
         // ---- slow path: too many centres around this tile (degenerate inputs).  Every lane
-        // walks the cell lists itself and flushes with global atomics.  Exact, just slower.
-        for (int sub = 0; sub < nsub; ++sub) {
-            const int y = y0 + sub * TH + wave * 4 + (lane >> 4);
-            uint32_t px[4];
-            load_px(y, px);
-            for (int j = 0; j < 4; ++j) {
-                if (!(y < H - 1 && x + j < W - 1)) continue;
-                const size_t li = ((size_t)b * H + y) * W + x + j;
-                typename KeyT<MODE == 2 ? 2 : 1>::type best = 0;
-                int bi = -1;
-                int4 qb = make_int4(0, 0, 0, 0);
-                for (int cyc = cyl; cyc <= cyh; ++cyc) {
-                    int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
-                    for (int i = beg; i < end; ++i) {
-                        int4 q = scand[i];
-                        if ((unsigned)(x + j - q.x + S) >= (unsigned)(2 * S) ||
-                            (unsigned)(y - q.y + S) >= (unsigned)(2 * S))
-                            continue;
-                        auto k = generic_key<MODE == 2 ? 2 : 1>(px[j], x + j, y, q.z, q.x, q.y, P);
-                        bool take = bi < 0 || k < best;
-                        if (!take && k == best) {
-                            // equal exact keys: the reference compares the rounded float64
-                            // values; on equality the lower centre index (earlier) stays
-                            double dn = literal_dist(px[j], x + j, y, q.z, q.x, q.y, P.Sd, P.cw);
-                            double db = literal_dist(px[j], x + j, y, qb.z, qb.x, qb.y, P.Sd, P.cw);
-                            take = dn < db || (dn == db && q.w < bi);
-                        }
-                        if (take) {
-                            best = k;
-                            bi = q.w;
-                            qb = q;
-                        }
+        // walks the cell lists itself for one pixel at a time and flushes with global atomics.
+        const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + TH * nsub - 1, H - 2);
+        const int4* scand = w.scand + (size_t)b * n;
+        const int* start = w.start + (size_t)b * (w.ncell + 1);
+        const int cxl = max(x0 - S + 1, 0) / S, cxh = min((x1 + S) / S, w.ncx - 1);
+        const int cyl = max(y0 - S + 1, 0) / S, cyh = min((y1 + S) / S, w.ncy - 1);
+        for (int y = y0 + (tid >> 6); y <= y1; y += 4) {
+            if (!colok) continue;
+            const size_t li = ((size_t)b * H + y) * W + x;
+            const uint8_t* q3 = lab + li * 3;
+            const uint32_t px = q3[0] | (q3[1] << 8) | (q3[2] << 16);
+            typename KeyT<MODE == 2 ? 2 : 1>::type best = 0;
+            int bi = -1;
+            int4 qb = make_int4(0, 0, 0, 0);
+            for (int cyc = cyl; cyc <= cyh; ++cyc) {
+                int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
+                for (int i = beg; i < end; ++i) {
+                    int4 q = scand[i];
+                    if ((unsigned)(x - q.x + S) >= (unsigned)(2 * S) ||
+                        (unsigned)(y - q.y + S) >= (unsigned)(2 * S))
+                        continue;
+                    auto k = generic_key<MODE == 2 ? 2 : 1>(px, x, y, q.z, q.x, q.y, P);
+                    bool take = bi < 0 || k < best;
+                    if (!take && k == best) {
+                        // equal exact keys: the reference compares the rounded float64
+                        // values; on equality the lower centre index (earlier) stays
+                        double dn = literal_dist(px, x, y, q.z, q.x, q.y, P.Sd, P.cw);
+                        double db = literal_dist(px, x, y, qb.z, qb.x, qb.y, P.Sd, P.cw);
+                        take = dn < db || (dn == db && q.w < bi);
+                    }
+                    if (take) {
+                        best = k;
+                        bi = q.w;
+                        qb = q;
                     }
                 }
-                int lbl = bi;
-                if (bi >= 0)
-                    labels[li] = bi;
-                else
-                    lbl = labels[li];
-                if (lbl >= 0) flush_pixel_global(sums, lbl, px[j], x + j, y);
             }
+            int lbl = bi;
+            if (bi >= 0)
+                labels[li] = bi;
+            else
+                lbl = labels[li];
+            if (lbl >= 0) flush_pixel_global(sums, lbl, px, x, y);
         }
         return;
     }
-
-    // ---- candidates into LDS, tile relative, with the per-candidate terms of the key
-    if (tid < m) {
-        int cxr = mine.x - x0, cyr = mine.y - y0;
-        uint32_t cl = (uint32_t)mine.z;
-        uint32_t A = 0;
-        int Bx = 0, By = 0;
-        if (MODE == 0) {
-            uint32_t cc = __builtin_amdgcn_udot4(cl, cl, 0u, false);
-            A = P.S2 * cc + P.cw2 * (uint32_t)(cxr * cxr + cyr * cyr);
-            Bx = 2 * (int)P.cw2 * cxr;
-            By = 2 * (int)P.cw2 * cyr;
-        }
-        s_c0[tid] = make_int4(cxr, cyr, (int)cl, (int)A);
-        s_c1[tid] = make_int4(Bx, By, mine.w, 0);
-    }
     __syncthreads();
 
-    const unsigned twoS = 2u * S;
-    const int S2x2 = 2 * (int)P.S2;
+    const int twoS = 2 * S;
+    const int nS2x2 = -2 * (int)P.S2;
+    uint32_t* trw = tr + wave * 256;
     for (int sub = 0; sub < nsub; ++sub) {
-        const int yr = sub * TH + wave * 4 + (lane >> 4);       // tile relative row
-        const int y = y0 + yr;
-        const int wy0 = sub * TH + wave * 4;                      // rows wy0..wy0+3 in this wave
-        if (y0 + wy0 >= H - 1) continue;                          // whole wave below the image
+        const int wy0 = sub * TH + wave * 4;             // tile relative first row of this wave
+        if (y0 + wy0 >= H - 1) continue;                 // whole wave below the image
         uint32_t px[4];
         if (ALIGNED) {
             Dword3 v = raw[0];
 #pragma unroll
             for (int k = 1; k < NSUBMAX; ++k)
                 if (sub == k) v = raw[k];
-            unpack(v, px);
-        } else {
-            load_px(y, px);
-        }
-        const bool rowok = (y < H - 1);
-        bool valid[4];
+            uint32_t q[4];
+            unpack(v, q);
+            // LDS operations of one wave complete in order: no barrier between the row-major
+            // store and the column reads, nor before the next band overwrites the patch
+            *reinterpret_cast<uint4*>(trw + (lane >> 4) * 64 + (lane & 15) * 4) =
+                make_uint4(q[0], q[1], q[2], q[3]);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) valid[j] = rowok && (x + j < W - 1);
-        const size_t lbase = ((size_t)b * H + y) * W + x;
-
-        int slot[4] = {-1, -1, -1, -1};
-        unsigned tied = 0;                  // bit j: the best key of pixel j was met again
-        if (MODE == 0) {
-            // Branch-free inner loop (selects only): per pixel and candidate one dot4, one
-            // 24-bit mad, one add for the key; the window test and the running minimum are
-            // compares + selects.  tc[j] counts how often the current best key was met again.
-            uint32_t best[4], T[4], tc[4];
+            for (int j = 0; j < 4; ++j) px[j] = trw[j * 64 + lane];
+            __builtin_amdgcn_wave_barrier();
+        } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                best[j] = 0xffffffffu;
-                tc[j] = 0;
-                uint32_t pp = __builtin_amdgcn_udot4(px[j], px[j], 0u, false);
-                T[j] = pp * P.S2 + P.cw2 * (uint32_t)((xr + j) * (xr + j) + yr * yr);
+                px[j] = 0;
+                const int yy = y0 + wy0 + j;
+                if (yy < H - 1 && colok) {
+                    const uint8_t* q = lab + (((size_t)b * H + yy) * W + x) * 3;
+                    px[j] = q[0] | (q[1] << 8) | (q[2] << 16);
+                }
             }
-            for (int s = 0; s < m; ++s) {
-                const int4 c0 = s_c0[s];
-                if (c0.y - S > wy0 + 3 || c0.y + S - 1 < wy0) continue;     // wave-level cull
-                const int2 bxy = *reinterpret_cast<const int2*>(&s_c1[s]);
-                const bool iny = (unsigned)(yr - c0.y + S) < twoS;
-                const int d0 = xr - c0.x + S;
-                // R + T = key without the colour dot product and the x cross term
-                const uint32_t Q0 = (uint32_t)c0.w - (uint32_t)__mul24(bxy.y, yr) -
-                                    (uint32_t)__mul24(bxy.x, xr);
-                const uint32_t cl = (uint32_t)c0.z;
+        }
+
+        int slot[4] = {-1, -1, -1, -1};
+        unsigned tied = 0;                  // bit j: the best key of pixel j may have been met again
+        if (MODE == 0) {
+            int best[4];
+            uint32_t T[4];
+            unsigned long long tie[4];      // lane masks (wave uniform values: scalar registers)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                best[j] = REL ? 0x7fffffff : -1;
+                tie[j] = 0ull;
+                T[j] = 0;
+                if (!REL) {
+                    const uint32_t pp = __builtin_amdgcn_udot4(px[j], px[j], 0u, false);
+                    T[j] = pp * P.S2 + P.cw2 * (uint32_t)(xr * xr + (wy0 + j) * (wy0 + j));
+                }
+            }
+            // No divergent branches in the loop: the column test (per lane) and the row tests
+            // (wave uniform) are lane masks in scalar registers that are and-ed into the
+            // compare results.  ALL: every row of the wave is inside the candidate's window
+            // (the common case), so only the column mask is left.
+            auto eval = [&](int s, const int8v& c, int t0, bool all_rows) {
+                const unsigned long long inxm =
+                    __builtin_amdgcn_ballot_w64((unsigned)(xr - c[0] + S) < (unsigned)twoS);
+                const int X = __mul24(-c[5], xr);
+                const int q0 = c[4] - c[6] * wy0;
+                const uint32_t cl = (uint32_t)c[2];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const uint32_t pc = __builtin_amdgcn_udot4(px[j], cl, 0u, false);
-                    const uint32_t base = T[j] + (Q0 - (uint32_t)(j * bxy.x));
-                    const uint32_t key = (uint32_t)(__mul24(-S2x2, (int)pc) + (int)base);
-                    const bool in = iny & ((unsigned)(d0 + j) < twoS);
-                    const bool lt = in & (key < best[j]);
-                    const bool eq = in & (key == best[j]);
-                    tc[j] = lt ? 0u : tc[j] + (eq ? 1u : 0u);
+                    const unsigned long long inm =
+                        (all_rows || (unsigned)(t0 + j) < (unsigned)twoS) ? inxm : 0ull;
+                    const int pc = (int)__builtin_amdgcn_udot4(px[j], cl, 0u, false);
+                    int key = __mul24(nS2x2, pc) + (X + (q0 - j * c[6]));
+                    if (!REL) key = (int)((uint32_t)key + T[j]);
+                    const unsigned long long ltm = __builtin_amdgcn_ballot_w64(
+                        REL ? key < best[j] : (uint32_t)key < (uint32_t)best[j]);
+                    // a key equal to the running best: flagged even when the candidate's window
+                    // does not hold the pixel (harmless, the replay below is exact)
+                    tie[j] |= __builtin_amdgcn_ballot_w64(key == best[j]);
+                    const bool lt = __builtin_amdgcn_inverse_ballot_w64(ltm & inm);
                     best[j] = lt ? key : best[j];
                     slot[j] = lt ? s : slot[j];
                 }
+            };
+            for (int s = 0; s < m; ++s) {
+                const int8v c = rec[1 + s];
+                const int t0 = wy0 - c[1] + S;           // row j is inside iff 0 <= t0 + j < 2S
+                if (t0 + 3 < 0 || t0 >= twoS) continue;  // no row of this wave inside
+                if (t0 >= 0 && t0 + 3 < twoS)
+                    eval(s, c, t0, true);
+                else
+                    eval(s, c, t0, false);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tied |= (tc[j] != 0u && slot[j] >= 0) ? (1u << j) : 0u;
+            for (int j = 0; j < 4; ++j)
+                tied |= (((tie[j] >> lane) & 1ull) != 0ull && slot[j] >= 0) ? (1u << j) : 0u;
         } else {
             typename KeyT<MODE>::type best[4];
             for (int s = 0; s < m; ++s) {
-                const int4 c0 = s_c0[s];
-                const bool iny = (unsigned)(yr - c0.y + S) < twoS;
+                const int4 c0 = s_c[s];
+                const bool inx = (unsigned)(xr - c0.x + S) < (unsigned)twoS;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bool in = iny && ((unsigned)(xr + j - c0.x + S) < twoS);
+                    bool in = inx && ((unsigned)(wy0 + j - c0.y + S) < (unsigned)twoS);
                     if (!in) continue;
-                    auto key = generic_key<MODE>(px[j], xr + j, yr, (uint32_t)c0.z, c0.x, c0.y, P);
+                    auto key = generic_key<MODE>(px[j], xr, wy0 + j, (uint32_t)c0.z, c0.x, c0.y, P);
                     if (slot[j] < 0 || key < best[j]) {
                         best[j] = key;
                         slot[j] = s;
@@ -542,17 +564,19 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (!((tied >> j) & 1u)) continue;
-                const int4 cb = s_c0[slot[j]];
-                const auto kbest = generic_key<1>(px[j], xr + j, yr, (uint32_t)cb.z, cb.x, cb.y, P);
+                const int yr = wy0 + j;
+                const int4 cb = s_c[slot[j]];
+                const auto kbest = generic_key<1>(px[j], xr, yr, (uint32_t)cb.z, cb.x, cb.y, P);
                 double dbest = 0.0;
                 int sb = -1;
                 for (int s = 0; s < m; ++s) {
-                    const int4 c0 = s_c0[s];
-                    if ((unsigned)(yr - c0.y + S) >= twoS || (unsigned)(xr + j - c0.x + S) >= twoS)
+                    const int4 c0 = s_c[s];
+                    if ((unsigned)(yr - c0.y + S) >= (unsigned)twoS ||
+                        (unsigned)(xr - c0.x + S) >= (unsigned)twoS)
                         continue;
-                    if (generic_key<1>(px[j], xr + j, yr, (uint32_t)c0.z, c0.x, c0.y, P) != kbest)
+                    if (generic_key<1>(px[j], xr, yr, (uint32_t)c0.z, c0.x, c0.y, P) != kbest)
                         continue;
-                    double d = literal_dist(px[j], xr + j, yr, (uint32_t)c0.z, c0.x, c0.y, P.Sd, P.cw);
+                    double d = literal_dist(px[j], xr, yr, (uint32_t)c0.z, c0.x, c0.y, P.Sd, P.cw);
                     if (sb < 0 || d < dbest) {
                         dbest = d;
                         sb = s;
@@ -562,30 +586,22 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
             }
         }
 
-        // ---- labels out + accumulate
-        bool all4 = true;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) all4 = all4 && valid[j] && slot[j] >= 0;
-        if (ALIGNED && all4) {
-            int4 o = make_int4(s_c1[slot[0]].z, s_c1[slot[1]].z, s_c1[slot[2]].z, s_c1[slot[3]].z);
-            *reinterpret_cast<int4*>(labels + lbase) = o;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (valid[j] && slot[j] >= 0) labels[lbase + j] = s_c1[slot[j]].z;
-        }
+        // ---- labels out + accumulate (a row of 64 labels per store instruction)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (!valid[j]) continue;
+            const int yr = wy0 + j, y = y0 + yr;
+            if (!(y < H - 1 && colok)) continue;
+            const size_t li = ((size_t)b * H + y) * W + x;
             if (slot[j] >= 0) {
-                uint32_t p = px[j];
+                labels[li] = s_c[slot[j]].w;
+                const uint32_t p = px[j];
                 uint32_t* a = acc + slot[j] * 192 + lane;
                 atomicAdd(a, (p & 0xffu) | ((p & 0xff00u) << 8));
                 atomicAdd(a + 64, ((p >> 16) & 0xffu) | 0x10000u);
-                atomicAdd(a + 128, (uint32_t)(xr + j) | ((uint32_t)yr << 16));
+                atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)yr << 16));
             } else {
-                int old = labels[lbase + j];      // not covered this round: keeps its label
-                if (old >= 0) flush_pixel_global(sums, old, px[j], x + j, y);
+                const int old = labels[li];           // not covered this round: keeps its label
+                if (old >= 0) flush_pixel_global(sums, old, px[j], x, y);
             }
         }
     }
@@ -593,7 +609,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
 
     // ---- reduce the 64 lane-private copies and flush: 16 lanes per slot = 4 lanes for each of
     // its 3 packed rows (L|a, b|count, x'|y'), 16 copies per lane.  A copy holds at most
-    // 4 waves x 4 bands x 4 pixels = 64 pixels, so its 16-bit halves cannot overflow
+    // 4 waves x 4 bands x 4 rows = 64 pixels, so its 16-bit halves cannot overflow
     // (64 * 255 < 65536); the halves are widened before they are summed.
     for (int s0 = 0; s0 < m; s0 += 16) {
         const int s = s0 + (tid >> 4), r = (tid >> 2) & 3, q = tid & 3;
@@ -614,7 +630,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
         hi += __shfl_xor(hi, 2);
         const uint32_t cnt = __shfl(hi, (lane & 48) + 4);      // row 1 of this slot: b | count
         if (live && q == 0 && cnt) {
-            unsigned long long* dst = sums + (size_t)s_c1[s].z * NFIELD;
+            unsigned long long* dst = sums + (size_t)s_c[s].w * NFIELD;
             if (r == 0) {
                 atomicAdd(&dst[0], (unsigned long long)lo);
                 atomicAdd(&dst[1], (unsigned long long)hi);
@@ -640,12 +656,17 @@ __global__ void slic_finalise_kernel(int32_t* __restrict__ centres, Ws w, int B,
     for (int k = 0; k < 5; ++k) o[k] = cnt ? (int32_t)(s[k] / cnt) : 0;
 }
 
-int key_mode(int S, double cw) {
+// 0: 32-bit key, 1: u64 key, 2: literal float64 (non-integral colour weight).  *rel: the
+// 32-bit key also fits a signed word once its per-pixel constant is dropped.
+int key_mode(int S, double cw, bool* rel) {
+    *rel = false;
     double r = rint(cw);
     if (r != cw || cw < 1.0 || cw > 4096.0) return 2;
     double cw2 = cw * cw, S2 = (double)S * S;
-    bool fits32 = S2 * (195075.0 + 2.0 * cw2) < 4294967295.0 &&
+    double span = (double)(TW + S) * (TW + S) + (double)(4 * TH + S) * (4 * TH + S);
+    bool fits32 = S2 * 195075.0 + cw2 * span < 4294967295.0 &&
                   2.0 * cw2 * (4 * TH + TW + S) < 8388608.0 && 2.0 * S2 < 8388608.0;
+    *rel = fits32 && S2 * 195075.0 + cw2 * span < 2147483647.0;
     return fits32 ? 0 : 1;
 }
 
@@ -713,9 +734,6 @@ extern "C" int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres
                        centres, w, B, H, W, S, n);
     hipLaunchKernelGGL(slic_scan_kernel, dim3(B), dim3(1024), 0, st, w);
     hipLaunchKernelGGL(slic_fill_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, w, B, n);
-    long long ntiles = (long long)B * L.ntx * L.nty;
-    hipLaunchKernelGGL(slic_tiles_kernel, dim3((unsigned)imgan::cdiv(ntiles, 4)), dim3(256), 0, st,
-                       w, B, H, W, S, n);
     return imgan::check_launch("slic_bin_centres");
 }
 
@@ -733,7 +751,8 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
     P.B = B; P.H = H; P.W = W; P.S = S; P.n = n;
     P.Sd = (double)S;
     P.cw = colour_weight;
-    int mode = key_mode(S, colour_weight);
+    bool rel = false;
+    int mode = key_mode(S, colour_weight, &rel);
     P.S2 = (unsigned)(S * S);
     P.cw2 = mode == 2 ? 0u : (unsigned)(colour_weight * colour_weight);
     bool aligned = (W % 4 == 0) && (((uintptr_t)lab & 3) == 0) && (((uintptr_t)labels & 15) == 0);
@@ -741,14 +760,18 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
     // LDS is sized for about twice the expected number of centres around a tile
     double m_est = (double)(TW + 2 * S) * (TH * L.nsub + 2 * S) / ((double)S * S);
     P.maxc = std::min(MAXC, std::max(16, ((int)(2.0 * m_est) + 4 + 7) / 8 * 8));
-    size_t lds_bytes = (size_t)P.maxc * (2 * sizeof(int4) + 3 * 64 * sizeof(uint32_t));
+    size_t lds_bytes = (size_t)P.maxc * (sizeof(int4) + 3 * 64 * sizeof(uint32_t)) + 4 * 256 * 4;
     dim3 grid((unsigned)L.ntx, (unsigned)L.nty, (unsigned)B);
     IMGAN_REQUIRE(grid.y <= 65535, "imgan_slic_assign_accumulate: image too tall");
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(M, A) hipLaunchKernelGGL((slic_assign_kernel<M, A>), grid, dim3(256), lds_bytes, st, lab, labels, w, P)
-    if (mode == 0) { if (aligned) LAUNCH(0, true); else LAUNCH(0, false); }
-    else if (mode == 1) { if (aligned) LAUNCH(1, true); else LAUNCH(1, false); }
-    else { if (aligned) LAUNCH(2, true); else LAUNCH(2, false); }
+    long long ntiles = (long long)B * L.ntx * L.nty;
+    hipLaunchKernelGGL(slic_tiles_kernel, dim3((unsigned)imgan::cdiv(ntiles, 4)), dim3(256), 0, st,
+                       w, P);
+#define LAUNCH(M, A, R) hipLaunchKernelGGL((slic_assign_kernel<M, A, R>), grid, dim3(256), lds_bytes, st, lab, labels, w, P)
+    if (mode == 0 && rel) { if (aligned) LAUNCH(0, true, true); else LAUNCH(0, false, true); }
+    else if (mode == 0) { if (aligned) LAUNCH(0, true, false); else LAUNCH(0, false, false); }
+    else if (mode == 1) { if (aligned) LAUNCH(1, true, false); else LAUNCH(1, false, false); }
+    else { if (aligned) LAUNCH(2, true, false); else LAUNCH(2, false, false); }
 #undef LAUNCH
     return imgan::check_launch("slic_assign_kernel");
 }
