@@ -54,6 +54,21 @@ def synth_batch(B, H, W, K, seed, device):
     return out
 
 
+def measured_traffic(B, H, W, K):
+    """HBM bytes per slic_assign_kernel launch from the rocprofv3 PMC passes committed under
+    profiles/ (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE),
+    scaled to this batch; null when no pass exists for this image size."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    e = t.get("%dx%d_K%d" % (W, H, K), {}).get("slic_assign_kernel")
+    if not e:
+        return None
+    return int(e["bytes_per_px"] * B * H * W)
+
+
 def cpu_baseline(H, W, K, cw):
     """The oracle (numpy restatement with the reference's cost structure, slic.py:88-126:
     per-centre window ops + per-label full-image scans) on a bounded sample."""
@@ -128,10 +143,34 @@ def main():
 
     if rank == 0:
         npix = B * H * W
-        ms = [e0.elapsed_time(e1) for e0, e1 in pipe.assign_events]
-        avg_ms = float(np.mean(ms))
+        stage_ms = pipe.stage_times_ms()           # HIP events on the launch stream, per C call
+        avg_ms = stage_ms["slic_assign"]
         algo = SLIC_ROUND_BYTES_PER_PX * npix
         achieved = algo / (avg_ms * 1e-3) / 1e9
+        # mean Lloyd rounds per pixel (a segment stops at its own round): the T of SURVEY 8d
+        t_bar = pipe.mean_lloyd_rounds()
+        traffic = measured_traffic(B, H, W, K)
+
+        def line(kernel, ms, bytes_px, bound="hbm", note=None):
+            ach = bytes_px * npix / (ms * 1e-3) / 1e9
+            d = {"kernel": kernel, "bound": bound, "launch_ms": round(ms, 4), "bytes_per_px": bytes_px,
+                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ach / HBM_PEAK_GBS, 4)}
+            if note:
+                d["note"] = note
+            return d
+
+        dcd_survey = 8.0 * t_bar + 13.0
+        others = [
+            line("bgr2lab_kernel", stage_ms["bgr2lab"], 6),
+            line("dcd_segment_kernel (+bbox, features)", stage_ms["dcd"], round(dcd_survey, 1),
+                 note="SURVEY 8d figure 8*T+13*P with T=%.1f measured rounds/px, P=1; the Lloyd "
+                      "rounds run in LDS, compulsory HBM traffic is 8 B/px (VALU/LDS bound)" % t_bar),
+            line("csd_kernel", stage_ms["csd"], 3),
+            line("cld_sums_kernel (+finalise)", stage_ms["cld"], 3),
+            line("ehd_sums_kernel (+classify)", stage_ms["ehd"], 3),
+        ]
+        path_bytes_px = 6 + 63 + 9 + dcd_survey
         out = {
             "metric": "megapixels/sec (SLIC+RAG+MPEG-7) at 1/2/4/8 GPUs; % HBM roofline",
             "value": round(world * npix * args.steps / dt / 1e6, 2),
@@ -144,12 +183,20 @@ def main():
                                    "num_iter=%d, cw=%d, %s" %
                                    (B, W, H, K, pipe.n, pipe.slic.S, num_iter, cw,
                                     "Lab + SLIC + CLD + EHD + CSD(256) + DCD(k=8 per superpixel, "
-                                    "%d Lloyd rounds)" % pipe.dcd_rounds_run),
+                                    "%.1f Lloyd rounds per pixel on chip)" % t_bar),
                        "global_batch": B * world, "parallelism": "batch-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "slic_assign_kernel", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "launch_ms": round(avg_ms, 4),
-                         "algorithmic_bytes_per_launch": algo},
+                         "traffic": traffic, "launch_ms": round(avg_ms, 4),
+                         "algorithmic_bytes_per_launch": algo,
+                         "launches_per_step": num_iter - 1},
+            "roofline_kernels": others,
+            "path": {"bytes_per_px": round(path_bytes_px, 1),
+                     "achieved": round(path_bytes_px * npix * args.steps / dt / 1e9 * 1.0, 1),
+                     "unit": "GB/s", "frac": round(path_bytes_px * npix * args.steps / dt / 1e9
+                                                   / HBM_PEAK_GBS, 4),
+                     "note": "whole step against SURVEY 8d's algorithmic bytes "
+                             "(6 Lab + 63 SLIC + 9 CLD/EHD/CSD + DCD)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(H, W, K, cw)

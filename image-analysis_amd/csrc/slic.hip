@@ -719,13 +719,35 @@ extern "C" int imgan_slic_init(const uint8_t* lab, int B, int H, int W, int S, i
     return imgan::check_launch("slic_init_kernel");
 }
 
+// Kernel parameters shared by the tile-record and the assignment kernels.
+AssignParams make_params(int B, int H, int W, int S, int n, double colour_weight, const Layout& L,
+                         int* mode_out, bool* rel_out) {
+    AssignParams P;
+    P.B = B; P.H = H; P.W = W; P.S = S; P.n = n;
+    P.Sd = (double)S;
+    P.cw = colour_weight;
+    *mode_out = key_mode(S, colour_weight, rel_out);
+    P.S2 = (unsigned)(S * S);
+    P.cw2 = *mode_out == 2 ? 0u : (unsigned)(colour_weight * colour_weight);
+    P.nsub = L.nsub;
+    // LDS is sized for about twice the expected number of centres around a tile
+    double m_est = (double)(TW + 2 * S) * (TH * L.nsub + 2 * S) / ((double)S * S);
+    P.maxc = std::min(MAXC, std::max(16, ((int)(2.0 * m_est) + 4 + 7) / 8 * 8));
+    return P;
+}
+
 extern "C" int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres, int B, int H,
-                                      int W, int S, int n, void* workspace,
+                                      int W, int S, int n, double colour_weight, void* workspace,
                                       imgan_stream_t stream) {
     IMGAN_REQUIRE(lab && centres && workspace, "imgan_slic_bin_centres: null pointer");
     if (int rc = validate("imgan_slic_bin_centres", B, H, W, S, n)) return rc;
+    IMGAN_REQUIRE(colour_weight > 0.0 && isfinite(colour_weight),
+                  "imgan_slic_bin_centres: colour_weight must be positive");
     Layout L = make_layout(B, H, W, S, n);
     Ws w = bind(workspace, L);
+    int mode;
+    bool rel;
+    AssignParams P = make_params(B, H, W, S, n, colour_weight, L, &mode, &rel);
     hipStream_t st = (hipStream_t)stream;
     // count and fill are adjacent in the layout: one memset clears both
     IMGAN_HIP(hipMemsetAsync(w.count, 0, L.off_start - L.off_count, st));
@@ -734,6 +756,9 @@ extern "C" int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres
                        centres, w, B, H, W, S, n);
     hipLaunchKernelGGL(slic_scan_kernel, dim3(B), dim3(1024), 0, st, w);
     hipLaunchKernelGGL(slic_fill_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, w, B, n);
+    long long ntiles = (long long)B * L.ntx * L.nty;
+    hipLaunchKernelGGL(slic_tiles_kernel, dim3((unsigned)imgan::cdiv(ntiles, 4)), dim3(256), 0, st,
+                       w, P);
     return imgan::check_launch("slic_bin_centres");
 }
 
@@ -747,26 +772,14 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
     IMGAN_REQUIRE(B <= 65535, "imgan_slic_assign_accumulate: batch > 65535, split the call");
     Layout L = make_layout(B, H, W, S, n);
     Ws w = bind(workspace, L);
-    AssignParams P;
-    P.B = B; P.H = H; P.W = W; P.S = S; P.n = n;
-    P.Sd = (double)S;
-    P.cw = colour_weight;
-    bool rel = false;
-    int mode = key_mode(S, colour_weight, &rel);
-    P.S2 = (unsigned)(S * S);
-    P.cw2 = mode == 2 ? 0u : (unsigned)(colour_weight * colour_weight);
+    int mode;
+    bool rel;
+    AssignParams P = make_params(B, H, W, S, n, colour_weight, L, &mode, &rel);
     bool aligned = (W % 4 == 0) && (((uintptr_t)lab & 3) == 0) && (((uintptr_t)labels & 15) == 0);
-    P.nsub = L.nsub;
-    // LDS is sized for about twice the expected number of centres around a tile
-    double m_est = (double)(TW + 2 * S) * (TH * L.nsub + 2 * S) / ((double)S * S);
-    P.maxc = std::min(MAXC, std::max(16, ((int)(2.0 * m_est) + 4 + 7) / 8 * 8));
     size_t lds_bytes = (size_t)P.maxc * (sizeof(int4) + 3 * 64 * sizeof(uint32_t)) + 4 * 256 * 4;
     dim3 grid((unsigned)L.ntx, (unsigned)L.nty, (unsigned)B);
     IMGAN_REQUIRE(grid.y <= 65535, "imgan_slic_assign_accumulate: image too tall");
     hipStream_t st = (hipStream_t)stream;
-    long long ntiles = (long long)B * L.ntx * L.nty;
-    hipLaunchKernelGGL(slic_tiles_kernel, dim3((unsigned)imgan::cdiv(ntiles, 4)), dim3(256), 0, st,
-                       w, P);
 #define LAUNCH(M, A, R) hipLaunchKernelGGL((slic_assign_kernel<M, A, R>), grid, dim3(256), lds_bytes, st, lab, labels, w, P)
     if (mode == 0 && rel) { if (aligned) LAUNCH(0, true, true); else LAUNCH(0, false, true); }
     else if (mode == 0) { if (aligned) LAUNCH(0, true, false); else LAUNCH(0, false, false); }
@@ -793,7 +806,8 @@ extern "C" int imgan_slic_run(const uint8_t* lab, int B, int H, int W, int S, in
     if (int rc = imgan_slic_init(lab, B, H, W, S, nx, ny, centres, labels, workspace, stream))
         return rc;
     for (int it = 1; it < num_iter; ++it) {                  // slic.py:84 -> num_iter - 1 rounds
-        if (int rc = imgan_slic_bin_centres(lab, centres, B, H, W, S, n, workspace, stream))
+        if (int rc = imgan_slic_bin_centres(lab, centres, B, H, W, S, n, colour_weight, workspace,
+                                            stream))
             return rc;
         if (int rc = imgan_slic_assign_accumulate(lab, labels, B, H, W, S, n, colour_weight,
                                                   workspace, stream))

@@ -28,7 +28,7 @@ SIGNATURES = {
     "imgan_slic_init": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),
     "imgan_slic_bin_centres": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                       c_void_p, c_void_p]),
+                                       c_double, c_void_p, c_void_p]),
     "imgan_slic_assign_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                              c_double, c_void_p, c_void_p]),
     "imgan_slic_finalise_centres": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -123,8 +123,8 @@ class SlicPlan(object):
         recorded around the assignment kernel on the current stream (bench.py roofline)."""
         lab = self._check(lab)
         a = (self.B, self.H, self.W, self.S, self.n)
-        check(lib.imgan_slic_bin_centres(_ptr(lab), _ptr(self.centres), *a, _ptr(self.workspace),
-                                         _stream()))
+        check(lib.imgan_slic_bin_centres(_ptr(lab), _ptr(self.centres), *a, float(colour_weight),
+                                         _ptr(self.workspace), _stream()))
         if events:
             events[0].record()
         check(lib.imgan_slic_assign_accumulate(_ptr(lab), _ptr(self.labels), *a,

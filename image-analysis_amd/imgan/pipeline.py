@@ -29,38 +29,67 @@ class FullPipeline(object):
         self.centres = torch.empty((self.B, self.n, self.k, 3), dtype=torch.float32, device=dev)
         self.features = torch.empty((self.B, self.n, self.k, 8), dtype=torch.float32, device=dev)
         self.assign_events = []
+        self.stage_events = {}
         self.dcd_rounds_run = 0
 
+    def _timed(self, name, timed, fn):
+        """Runs fn(); with timed, brackets it with events on the current (launch) stream."""
+        if not timed:
+            return fn()
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        out = fn()
+        ev[1].record()
+        self.stage_events.setdefault(name, []).append(ev)
+        return out
+
     def run_slic(self, bgr, timed=False):
-        ops.bgr2lab(bgr, out=self.lab)
+        self._timed("bgr2lab", timed, lambda: ops.bgr2lab(bgr, out=self.lab))
         self.slic.init(self.lab)
         for _ in range(1, self.num_iter):
             if timed:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 self.slic.round(self.lab, self.cw, events=ev)
-                self.assign_events.append(ev)
+                self.stage_events.setdefault("slic_assign", []).append(ev)
             else:
                 self.slic.round(self.lab, self.cw)
         return self.slic.labels
 
-    def run_dcd(self):
+    def run_dcd(self, timed=False):
         labels = self.slic.labels
         p = ops._ptr
-        self.dcd.kmeans(self.lab, labels, self.centres, seed=self.seed, max_rounds=self.max_rounds,
-                        check_every=self.check_every)
-        self.dcd_rounds_run = self.dcd.rounds_run
-        stats = self.dcd.statistics(self.lab, labels)
-        check(lib.imgan_dcd_features(p(stats), p(self.centres), self.B, self.n, self.k,
-                                     p(self.features), ops._stream()))
+
+        def go():
+            self.dcd.kmeans(self.lab, labels, self.centres, seed=self.seed,
+                            max_rounds=self.max_rounds, check_every=self.check_every)
+            self.dcd_rounds_run = self.dcd.rounds_run
+            stats = self.dcd.statistics(self.lab, labels)
+            check(lib.imgan_dcd_features(p(stats), p(self.centres), self.B, self.n, self.k,
+                                         p(self.features), ops._stream()))
+        self._timed("dcd", timed, go)
         return self.features
 
     def step(self, bgr, timed=False):
         """One pass of the whole path over the resident batch.
         Returns (image_rows int32 [B, 12+80+16+csd_bins+1], region_rows float32 [B, n*k*8])."""
         self.run_slic(bgr, timed)
-        cld = self.desc.colour_layout(bgr)
-        ehd = self.desc.edge_histogram(bgr)
-        csd = self.desc.colour_structure(bgr)
-        feats = self.run_dcd()
+        cld = self._timed("cld", timed, lambda: self.desc.colour_layout(bgr))
+        ehd = self._timed("ehd", timed, lambda: self.desc.edge_histogram(bgr))
+        csd = self._timed("csd", timed, lambda: self.desc.colour_structure(bgr))
+        feats = self.run_dcd(timed)
         image_rows = torch.cat([cld[:, 0, :6], cld[:, 1, :3], cld[:, 2, :3], ehd, csd], dim=1)
         return image_rows, feats.view(self.B, -1)
+
+    def stage_times_ms(self):
+        """Mean device time per C call of every stage recorded with timed=True."""
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v)
+                for k, v in self.stage_events.items()}
+
+    def mean_lloyd_rounds(self):
+        """Pixel-weighted mean number of Lloyd rounds of the last dominant-colour pass."""
+        rounds, _ = self.dcd.rounds()
+        npx = self.dcd.stats[..., 0].sum(dim=2).to(torch.float64)
+        tot = float(npx.sum().item())
+        r = float((rounds.to(torch.float64) * npx).sum().item()) / max(tot, 1.0)
+        return max(r, float(self.dcd_rounds_run))

@@ -64,9 +64,12 @@ size_t imgan_slic_workspace_bytes(int B, int H, int W, int S, int n);
 int imgan_slic_init(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,
                     int32_t* centres, int32_t* labels, void* workspace, imgan_stream_t stream);
 
-/* Re-bin the centres into S x S cells (candidate lookup for the next assignment). */
+/* Candidate lookup for the next assignment: re-bins the centres into S x S cells and writes,
+ * for every 64-pixel-wide tile, the sorted list of centres whose window (slic.py:94-100) can
+ * reach it, with the per-centre terms of the distance of slic.py:101-109 (hence the colour
+ * weight).  The reference has no counterpart: it loops over centres instead (slic.py:88). */
 int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres, int B, int H, int W, int S,
-                           int n, void* workspace, imgan_stream_t stream);
+                           int n, double colour_weight, void* workspace, imgan_stream_t stream);
 
 /* slic.py:85-116 (assignment over the 2S x 2S windows) fused with the sums of
  * :118-125.  colour_weight: slic.py:109.  Labels are updated in place. */
