@@ -46,8 +46,11 @@ def synth_batch(B, H, W, K, seed, device):
         sx = torch.rand(ns, generator=g, device=device) * W
         sy = torch.rand(ns, generator=g, device=device) * H
         cols = torch.randint(0, 256, (ns, 3), generator=g, device=device).float()
-        d = (xx - sx.view(1, 1, ns)) ** 2 + (yy - sy.view(1, 1, ns)) ** 2
-        idx = d.argmin(dim=2)
+        # nearest site per grid point, in row chunks (the 16384^2 / 25,000-site mosaic would
+        # need 400 GB as one [hs, ws, ns] tensor)
+        rows = max(1, (1 << 28) // (ws * ns))
+        idx = torch.cat([((xx - sx.view(1, 1, ns)) ** 2 + (yy[r:r + rows] - sy.view(1, 1, ns)) ** 2)
+                         .argmin(dim=2) for r in range(0, hs, rows)], dim=0)
         idx = idx.repeat_interleave(sub, 0).repeat_interleave(sub, 1)[:H, :W]
         img = cols[idx] + torch.randn((H, W, 3), generator=g, device=device) * 8.0
         out[b] = img.round().clamp_(0, 255).to(torch.uint8)
