@@ -27,6 +27,21 @@ def _synth(B, H, W, K, seed):
     return synth_batch(B, H, W, K, seed, "cuda")
 
 
+def _segment_sums(torch, keys, values, n):
+    """Counts and per-key integer sums of `values` (list of 1-D tensors) for keys in [0, n).
+    Sort + prefix sums: torch.bincount with weights crawls on spatially coherent label maps
+    (every lane of a wave adds to the same address)."""
+    skeys, perm = torch.sort(keys.long())
+    edges = torch.searchsorted(skeys, torch.arange(n + 1, device=keys.device))
+    cnt = edges[1:] - edges[:-1]
+    out = []
+    for v in values:
+        cs = torch.cat([torch.zeros(1, dtype=torch.long, device=keys.device),
+                        torch.cumsum(v[perm].long(), 0)])
+        out.append(cs[edges[1:]] - cs[edges[:-1]])
+    return cnt, out
+
+
 def _slic_rounds(plan, lab, cw, num_iter):
     """init + (num_iter-1) rounds; returns the centres that the LAST assignment used."""
     plan.init(lab)
@@ -97,10 +112,9 @@ def _check_slic(torch, B, H, W, K, cw=15, num_iter=10, nsample=2048, seed=99):
         ok = lb >= 0
         yy, xx = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"),
                                 indexing="ij")
-        cnt = torch.bincount(lb[ok], minlength=n)
-        vals = [lab[b, :, :, c].reshape(-1) for c in range(3)] + [xx.reshape(-1), yy.reshape(-1)]
-        for f, v in enumerate(vals):
-            s = torch.bincount(lb[ok], weights=v[ok].double(), minlength=n).long()
+        vals = [lab[b, :, :, c].reshape(-1)[ok] for c in range(3)] + [xx.reshape(-1)[ok], yy.reshape(-1)[ok]]
+        cnt, sums = _segment_sums(torch, lb[ok], vals, n)
+        for f, s in enumerate(sums):
             want = torch.where(cnt > 0, s // cnt.clamp(min=1), torch.zeros_like(s))
             assert torch.equal(want.int(), centres[b, :, f]), (b, f)
 
@@ -134,9 +148,7 @@ def _torch_rag(torch, img_b, labels_b, K):
     H, W = labels_b.shape
     lb = labels_b.view(-1)
     ok = (lb >= 0) & (lb < K)
-    cnt = torch.bincount(lb[ok], minlength=K)
-    sums = [torch.bincount(lb[ok], weights=img_b[:, :, c].reshape(-1)[ok].double(), minlength=K).long()
-            for c in range(3)]
+    cnt, sums = _segment_sums(torch, lb[ok], [img_b[:, :, c].reshape(-1)[ok] for c in range(3)], K)
     keys = []
     L = labels_b.long()
     for dy, dx in ((0, 1), (1, 0), (1, 1), (1, -1)):
@@ -197,16 +209,15 @@ def test_mosaic_16k_superpixel_descriptors():
     torch.cuda.synchronize()
     lb = labels[0].view(-1)
     ok = lb >= 0
-    seg_px = torch.bincount(lb[ok], minlength=n)
+    seg_px, seg_sums = _segment_sums(torch, lb[ok], [lab[0, :, :, c].reshape(-1)[ok] for c in range(3)], n)
     assert torch.equal(stats[0, :, :, 0].sum(dim=1), seg_px)     # every pixel in one cluster
     for c in range(3):
-        s = torch.bincount(lb[ok], weights=lab[0, :, :, c].reshape(-1)[ok].double(), minlength=n).long()
-        assert torch.equal(stats[0, :, :, 1 + c].sum(dim=1), s)
+        assert torch.equal(stats[0, :, :, 1 + c].sum(dim=1), seg_sums[c])
     a = dcd.assign[0].view(-1)
     assert bool((a[ok] < k).all()) and bool((a[~ok] == 0xff).all())
     # per (segment, cluster) counts recomputed from the assignment map
     pair = lb[ok].long() * k + a[ok].long()
-    assert torch.equal(torch.bincount(pair, minlength=n * k).view(n, k), stats[0, :, :, 0])
+    assert torch.equal(_segment_sums(torch, pair, [], n * k)[0].view(n, k), stats[0, :, :, 0])
     # largest component is at least one pixel and at most the cluster size
     big = stats[0, :, :, 7]
     cnt = stats[0, :, :, 0]
