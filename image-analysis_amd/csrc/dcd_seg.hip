@@ -714,3 +714,18 @@ extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int
 #undef TIER
     return imgan::check_launch("imgan_dcd_segments");
 }
+
+extern "C" int imgan_label_bbox(const int32_t* labels, int B, int H, int W, int nseg,
+                                int32_t* bbox, imgan_stream_t stream) {
+    IMGAN_REQUIRE(labels && bbox, "imgan_label_bbox: null pointer");
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535, "imgan_label_bbox: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    size_t nsegs = (size_t)B * nseg;
+    IMGAN_REQUIRE(nsegs < 0x7fffffffULL, "imgan_label_bbox: too many segments");
+    hipLaunchKernelGGL(seg_bbox_init_kernel, dim3((unsigned)imgan::cdiv((long long)nsegs, 256)),
+                       dim3(256), 0, st, bbox, (int)nsegs);
+    dim3 gb((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, BBOX_ROWS), (unsigned)B);
+    IMGAN_REQUIRE(gb.y <= 65535, "imgan_label_bbox: image too tall");
+    hipLaunchKernelGGL(seg_bbox_kernel, gb, dim3(256), 0, st, labels, H, W, nseg, bbox);
+    return imgan::check_launch("seg_bbox_kernel");
+}

@@ -203,6 +203,29 @@ int imgan_csd(const uint8_t* bgr, int B, int H, int W, int nbins, int32_t* csd_o
 int imgan_hmmd_quantise(const uint8_t* bgr, uint8_t* out, int64_t npix, int nbins,
                         imgan_stream_t stream);
 
+/* ---- spatial relations (spatialextract.py) ------------------------------------
+ * imgan_label_bbox: bounding box of every label (cv2.boundingRect of the segment mask,
+ * spatialextract.py:9-11,47).  bbox: int32 [B][nseg][4] = xmin, ymin, xmax, ymax
+ * (xmax = -1 for a label without pixels).  Labels outside 0..nseg-1 are ignored. */
+int imgan_label_bbox(const int32_t* labels, int B, int H, int W, int nseg, int32_t* bbox,
+                     imgan_stream_t stream);
+
+/* spatialextract.py:25-38 and :71-171: label counts inside the compass sectors of a segment's
+ * enlarged box.  A sector is given as one or two "pieces" (column ranges); for column x of a
+ * piece the rows [lo(x), hi(x)) belong to the sector, each bound being a constant or
+ * int(a*x + b) in float64, optionally clamped against the constant.
+ *   pieces_i: int32 [npieces][8] = slot, sector (0..7), xa, xb, lo_kind, hi_kind, lo_c, hi_c
+ *   pieces_d: double [npieces][4] = lo_a, lo_b, hi_a, hi_b
+ *   kind: 0 = c, 1 = int(a*x+b), 2 = max(int(a*x+b), c), 3 = min(int(a*x+b), c)
+ * counts: int32 [nslots][8][nlab], zero-filled by the caller; counts[slot][sector][l] receives
+ * the number of sector pixels labelled l (labels outside 0..nlab-1 are not counted).
+ * max_cols: the widest piece (xb - xa).  oob_flag: device int32, zero-filled by the caller,
+ * set to 1 if a piece reaches outside the image (the reference would raise IndexError).
+ * labels: int32 [H][W] (one image). */
+int imgan_spatial_sectors(const int32_t* labels, int H, int W, int nlab, const int32_t* pieces_i,
+                          const double* pieces_d, int npieces, int max_cols, int32_t* counts,
+                          int32_t* oob_flag, imgan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
