@@ -38,6 +38,7 @@ __device__ unsigned long long seg_timing[16];
 #endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;   // one global_load_dword at any address
 
 constexpr int CAP_SMALL = 11776, THREADS_SMALL = 512;       // 6 B of LDS per pixel
 constexpr int CAP_LARGE = 22528, THREADS_LARGE = 1024;     // >= 4 S^2 of the 1080p / K=400 grid
@@ -250,9 +251,10 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
         // load under a branch makes the compiler wait for it at the join, which serialises
         // the batch and leaves the gather bound by 8 memory latencies per step).
         const float inv_bw = 1.0f / (float)bw;
+        const size_t last_px = (size_t)gridDim.y * H * W - 1;
         for (int i0 = 0; i0 < area; i0 += THREADS * 4) {
             int lbl[4], off[4];
-            uint32_t pp[4], r0[4], r1[4], r2[4];
+            uint32_t pp[4], raw[4], sh[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * THREADS + tid;
@@ -264,10 +266,11 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
                 xx = ic - yy * bw;
                 pp[u] = (uint32_t)((ymin + yy) * W + xmin + xx);
                 lbl[u] = labels[img + pp[u]];
-                const uint8_t* q = lab + (img + pp[u]) * 3;
-                r0[u] = q[0];
-                r1[u] = q[1];
-                r2[u] = q[2];
+                // the three Lab bytes with one (unaligned) dword load; the very last pixel of
+                // the batch is read one byte early so that the load stays inside the buffer
+                const size_t gp = img + pp[u];
+                sh[u] = gp == last_px ? 1u : 0u;
+                raw[u] = *reinterpret_cast<const u32_unaligned*>(lab + gp * 3 - sh[u]);
             }
             uint32_t v[4];
             int slot[4];
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
                     base = __shfl(base, leader);
                 }
                 slot[u] = base + __popcll(who & ((1ull << lane) - 1ull));
-                v[u] = r0[u] | (r1[u] << 8) | (r2[u] << 16);
+                v[u] = (raw[u] >> (8u * sh[u])) & 0xffffffu;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -684,6 +687,7 @@ extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int
                   "imgan_dcd_segments: bad shape");
     IMGAN_REQUIRE(k >= 1 && k <= KMAX, "imgan_dcd_segments: 1 <= k <= 16 dominant colours");
     IMGAN_REQUIRE((long long)H * W < 0x7fffffffLL, "imgan_dcd_segments: image too large");
+    IMGAN_REQUIRE((long long)B * H * W >= 2, "imgan_dcd_segments: needs at least two pixels");
     IMGAN_REQUIRE(max_rounds >= 1, "imgan_dcd_segments: max_rounds must be positive");
     hipStream_t st = (hipStream_t)stream;
     DcdLayout L = dcd_layout(B, nseg, k);
