@@ -4,8 +4,9 @@ Built in this round (HIP kernels through libimgan_hip.so):
   * dominant colour per segment          -- mpeg7Descriptors.py:76-141
   * colour layout, edge histogram, colour structure -- additive methods; the reference does
     not have them, they follow ISO/IEC 15938-3 as defined in DESIGN.md.
-Not built yet (SURVEY.md 8f "next" rows, raise NotImplementedError): homogeneous texture
-(:277-365) and region shape / ART (:144-275).
+  * region shape / ART                   -- mpeg7Descriptors.py:144-186, 233-275
+Not built yet (SURVEY.md 8f "next" row, raises NotImplementedError): homogeneous texture
+(:277-365).
 
 Deviations of dominant colour from the reference, all stated in DESIGN.md:
   * the reference samples the initial centres with an unseeded random.sample (:79); here the
@@ -157,14 +158,126 @@ class MPEG7Descriptors(object):
             return [int(v) for v in hist], nwin
         return csd_quantise(hist, nwin)
 
+    # ------------------------------------------------------------------ region shape (ART)
+    @staticmethod
+    def _polar_tables(height, width):
+        """Angle tables and radial scale of cart2radial (mpeg7Descriptors.py:153-162), float64."""
+        max_rad = np.sqrt(width ** 2 + height ** 2) / 2.0
+        r_scale = max_rad / width
+        ang_scale = (2 * np.pi) / height
+        angle = np.arange(height) * ang_scale
+        return np.cos(angle), np.sin(angle), float(r_scale)
+
+    @staticmethod
+    def _region_shape_device(grey_u8, label_map, nseg, want_polar):
+        """Runs imgan_region_shape; returns (art [nseg,3,12] float64, polar [nseg,H,W] u8 | None)."""
+        from imgan._lib import lib, check
+        H, W = grey_u8.shape
+        cos_t, sin_t, r_scale = MPEG7Descriptors._polar_tables(H, W)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        d_grey = torch.from_numpy(np.ascontiguousarray(grey_u8)).to(dev)
+        d_lab = torch.from_numpy(np.ascontiguousarray(label_map, dtype=np.int32)).to(dev)
+        d_cos, d_sin = torch.from_numpy(cos_t).to(dev), torch.from_numpy(sin_t).to(dev)
+        art = torch.empty((nseg, 36), dtype=torch.float64, device=dev)
+        polar = torch.empty((nseg, H, W), dtype=torch.uint8, device=dev) if want_polar else None
+        scratch = torch.empty(max(lib.imgan_region_shape_scratch_bytes(H, W, nseg), 8),
+                              dtype=torch.uint8, device=dev)
+        check(lib.imgan_region_shape(ops._ptr(d_grey), ops._ptr(d_lab), H, W, nseg, ops._ptr(d_cos),
+                                     ops._ptr(d_sin), r_scale,
+                                     ops._ptr(polar) if want_polar else None, ops._ptr(art),
+                                     ops._ptr(scratch), ops._stream()))
+        return (art.cpu().numpy().reshape(nseg, 3, 12),
+                polar.cpu().numpy() if want_polar else None)
+
+    @staticmethod
+    def cart2radial(image, one_dim=False, interp=True, dtype=np.uint8):
+        """mpeg7Descriptors.py:144-186.  interp=True (what art_transform uses) runs on the GPU,
+        channel by channel; the result is cast to `dtype` as the reference's blank image is."""
+        image = np.asarray(image)
+        if image.dtype != np.uint8:
+            raise ValueError("cart2radial expects an 8-bit image")
+        planes = [image] if one_dim else [image[:, :, c] for c in range(3)]
+        height, width = planes[0].shape
+        if interp:
+            none = np.full((height, width), -1, dtype=np.int32)       # grey outside every segment
+            out = [MPEG7Descriptors._region_shape_device(np.ascontiguousarray(p), none, 1, True)[1][0]
+                   for p in planes]
+        else:
+            # nearest sample (:181-184): plain numpy indexing, negative indices wrap as they do
+            # in the reference and an index equal to the size raises IndexError
+            cos_t, sin_t, r_scale = MPEG7Descriptors._polar_tables(height, width)
+            radius = np.arange(width) * r_scale
+            px = (radius[None, :] * cos_t[:, None] + width / 2.0).astype(np.int64)
+            py = (radius[None, :] * sin_t[:, None] + height / 2.0).astype(np.int64)
+            py = np.where(py <= height, py, height)
+            px = np.where(px <= width, px, width)
+            out = [p[py, px] for p in planes]
+        res = out[0] if one_dim else np.stack(out, axis=-1)
+        return res.astype(dtype)
+
+    @staticmethod
+    def polar2cart(pol_image, one_dim=False, interp=True, dtype=np.uint8):
+        """mpeg7Descriptors.py:189-231 (inverse mapping; not used by any descriptor, host numpy
+        kept for API parity).  Window means follow the same Python slice rules as cart2radial."""
+        pol_image = np.asarray(pol_image)
+        planes = [pol_image] if one_dim else [pol_image[:, :, c] for c in range(3)]
+        height, width = planes[0].shape
+        max_rad = np.sqrt(width ** 2 + height ** 2) / 2.0
+        r_scale = max_rad / width
+        ang_scale = (2 * np.pi) / height
+        dy = (np.arange(height) - height // 2)[:, None] * np.ones((1, width), dtype=np.int64)
+        dx = (np.arange(width) - width // 2)[None, :] * np.ones((height, 1), dtype=np.int64)
+        angle = np.arctan2(dy, dx) % (2 * np.pi)
+        radius = np.sqrt(dx ** 2 + dy ** 2)
+        iy = (angle / ang_scale).astype(np.int64)
+        ix = (radius / r_scale).astype(np.int64)
+        out = []
+        for p in planes:
+            if interp:
+                sat = np.zeros((height + 1, width + 1), dtype=np.int64)
+                sat[1:, 1:] = np.cumsum(np.cumsum(p.astype(np.int64), axis=0), axis=1)
+
+                def span(t, size):
+                    lo = np.maximum(t, 0)
+                    hi = np.where(t + 2 <= size, t + 2, size)
+                    hi = np.where(hi < 0, np.maximum(hi + size, 0), hi)
+                    lo = np.minimum(lo, size)
+                    return lo, np.maximum(hi, lo)
+                x0, x1 = span(ix, width)
+                y0, y1 = span(iy, height)
+                cnt = (x1 - x0) * (y1 - y0)
+                tot = sat[y1, x1] - sat[y0, x1] - sat[y1, x0] + sat[y0, x0]
+                out.append(np.where(cnt > 0, tot // np.maximum(cnt, 1), 0))
+            else:
+                yy = np.where(iy <= height, iy, height - 1)
+                xx = np.where(ix <= width, ix, width - 1)
+                out.append(p[yy, xx])
+        res = out[0] if one_dim else np.stack(out, axis=-1)
+        return res.astype(dtype)
+
+    def art_transform(self, image):
+        """mpeg7Descriptors.py:233-257: 3 x 12 ART magnitudes of an 8-bit H x W image."""
+        image = np.asarray(image)
+        if image.ndim != 2 or image.dtype != np.uint8:
+            raise ValueError("art_transform expects an 8-bit H x W image")
+        none = np.full(image.shape, -1, dtype=np.int32)
+        art, _ = self._region_shape_device(np.ascontiguousarray(image), none, 1, False)
+        return art[0].tolist()
+
+    def mpeg7_region_shape(self):
+        """mpeg7Descriptors.py:259-275: {segment: 3 x 12 list}.  As in the reference the
+        transform sees the whole frame (the bounding-box crop at :270-272 is never used): 1 on
+        the segment, 0 on other segments, the grey level on pixels outside every segment."""
+        segs, label_map = self._segment_index_map()
+        if not segs:
+            return {}
+        art, _ = self._region_shape_device(self.image_gray, label_map, len(segs), False)
+        return {int(seg): art[i].tolist() for i, seg in enumerate(segs)}
+
     # ------------------------------------------------------------------ next rows (8f)
     def mpeg7_homogeneus_texture(self):
         raise NotImplementedError("homogeneous texture (mpeg7Descriptors.py:277-365) is a "
                                   "later row of the build plan (SURVEY.md 8f); not built yet")
-
-    def mpeg7_region_shape(self):
-        raise NotImplementedError("region shape / ART (mpeg7Descriptors.py:233-275) is a later "
-                                  "row of the build plan (SURVEY.md 8f); not built yet")
 
 
 EHD_QUANT = [

@@ -226,6 +226,21 @@ int imgan_spatial_sectors(const int32_t* labels, int H, int W, int nlab, const i
                           const double* pieces_d, int npieces, int max_cols, int32_t* counts,
                           int32_t* oob_flag, imgan_stream_t stream);
 
+/* ---- region shape / ART (mpeg7Descriptors.py:144-186, 233-275) -----------------
+ * For every segment s in 0..nseg-1 of `labels` (int32 [H][W], one image): the value image is 1
+ * on the segment, the grey level where labels < 0 and 0 elsewhere (segment_generator :28-38
+ * followed by :264-266); cart2radial (:156-185, window means with Python slice rules) gives the
+ * polar image and art_transform (:239-256) the 3 x 12 magnitudes, normalised by [0][0].
+ * cos_tab / sin_tab: double [H] = cos / sin of y * 2 pi / H (device; computed by the caller so
+ * that the sample positions are the reference's bit for bit); r_scale = sqrt(W^2+H^2)/2/W (:153-154).
+ * polar_out: uint8 [nseg][H][W] or NULL; art_out: double [nseg][36] (n major);
+ * scratch: imgan_region_shape_scratch_bytes(H, W, nseg) bytes.
+ * nseg = 1 with labels all < 0 transforms `grey` itself (art_transform of a plain image). */
+size_t imgan_region_shape_scratch_bytes(int H, int W, int nseg);
+int imgan_region_shape(const uint8_t* grey, const int32_t* labels, int H, int W, int nseg,
+                       const double* cos_tab, const double* sin_tab, double r_scale,
+                       uint8_t* polar_out, double* art_out, void* scratch, imgan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
