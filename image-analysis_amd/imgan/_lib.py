@@ -65,6 +65,10 @@ SIGNATURES = {
     "imgan_region_shape_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "imgan_region_shape": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                    c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "imgan_texture_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "imgan_homogeneous_texture": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p]),
     "imgan_label_bbox": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "imgan_spatial_sectors": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                       c_int, c_void_p, c_void_p, c_void_p]),

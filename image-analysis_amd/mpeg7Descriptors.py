@@ -5,8 +5,7 @@ Built in this round (HIP kernels through libimgan_hip.so):
   * colour layout, edge histogram, colour structure -- additive methods; the reference does
     not have them, they follow ISO/IEC 15938-3 as defined in DESIGN.md.
   * region shape / ART                   -- mpeg7Descriptors.py:144-186, 233-275
-Not built yet (SURVEY.md 8f "next" row, raises NotImplementedError): homogeneous texture
-(:277-365).
+  * homogeneous texture (Radon + Gabor)  -- mpeg7Descriptors.py:277-365
 
 Deviations of dominant colour from the reference, all stated in DESIGN.md:
   * the reference samples the initial centres with an unseeded random.sample (:79); here the
@@ -22,6 +21,7 @@ import numpy as np
 import torch
 
 from imgan import ops
+from const_data import CEN_FREQ, OCT_BAND, ANGULAR_BAND, ANGULAR_CEN
 
 default_wres = 320
 gabor_radial = 5
@@ -274,10 +274,98 @@ class MPEG7Descriptors(object):
         art, _ = self._region_shape_device(self.image_gray, label_map, len(segs), False)
         return {int(seg): art[i].tolist() for i, seg in enumerate(segs)}
 
-    # ------------------------------------------------------------------ next rows (8f)
+    # ------------------------------------------------------------------ homogeneous texture
+    @staticmethod
+    def gabor_filters(num_rad, num_ang, plane_len):
+        """mpeg7Descriptors.py:287-305: the Gabor channel masks on the (angle, radius) plane
+        (host table generator, kept for API parity; the kernels evaluate the same expression)."""
+        ang_w, rad_h = plane_len
+        rad = lambda x: ((np.pi * x) / 180)
+        angle_p = np.array([(2 * np.pi * ang) / ang_w for ang in range(ang_w)])
+        radius_p = np.linspace(0, 1, rad_h)
+        radius_p, angle_p = np.meshgrid(radius_p, angle_p)
+        g_filter_list = []
+        for r_idx in range(num_rad):
+            for a_idx in range(num_ang):
+                rad_std = OCT_BAND[r_idx] / 2 * np.sqrt(2 * np.log(2))
+                ang_std = rad(ANGULAR_BAND[a_idx]) / 2 * np.sqrt(2 * np.log(2))
+                g_filter_list.append(
+                    np.exp((-((radius_p - 0.5) - CEN_FREQ[r_idx]) ** 2) / (2.0 * rad_std ** 2)) *
+                    np.exp((-(angle_p - rad(ANGULAR_CEN[a_idx])) ** 2) / (2.0 * ang_std ** 2)))
+        return g_filter_list
+
+    @staticmethod
+    def _texture_tables(side):
+        """Host tables of radon_feature_extract, float64, written as in the reference / scipy."""
+        from scipy import special
+        c_num = 329
+        rot = np.zeros((c_num, 6), dtype=np.float64)
+        centre = (np.asarray([side, side]) - 1) / 2
+        for per in range(c_num):
+            angle = np.rad2deg((np.pi * per) / c_num)                       # :326
+            c, s = special.cosdg(angle), special.sindg(angle)               # scipy.ndimage.rotate
+            m = np.array([[c, s], [-s, c]])
+            off = centre - m @ centre
+            rot[per] = [m[0, 0], m[0, 1], m[1, 0], m[1, 1], off[0], off[1]]
+        rad = lambda x: ((np.pi * x) / 180)
+        chan = np.zeros((gabor_radial * gabor_angular, 4), dtype=np.float64)
+        for r_idx in range(gabor_radial):
+            for a_idx in range(gabor_angular):
+                rad_std = OCT_BAND[r_idx] / 2 * np.sqrt(2 * np.log(2))      # :299-300
+                ang_std = rad(ANGULAR_BAND[a_idx]) / 2 * np.sqrt(2 * np.log(2))
+                chan[r_idx * gabor_angular + a_idx] = [CEN_FREQ[r_idx], 2.0 * rad_std ** 2,
+                                                       rad(ANGULAR_CEN[a_idx]), 2.0 * ang_std ** 2]
+        angle_p = np.array([(2 * np.pi * ang) / c_num for ang in range(c_num)])   # :344
+        radius_p = np.linspace(0, 1, side)                                         # :345
+        return rot, chan, angle_p, radius_p
+
+    @staticmethod
+    def _texture_device(grey_u8, label_map, nseg):
+        """Runs imgan_homogeneous_texture; returns one feature list per segment (:348-365)."""
+        from imgan._lib import lib, check
+        H, W = grey_u8.shape
+        tabs = MPEG7Descriptors._texture_tables(max(H, W))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        d_tabs = [torch.from_numpy(np.ascontiguousarray(t)).to(dev) for t in tabs]
+        d_grey = torch.from_numpy(np.ascontiguousarray(grey_u8)).to(dev)
+        d_lab = torch.from_numpy(np.ascontiguousarray(label_map, dtype=np.int32)).to(dev)
+        out = torch.zeros((nseg, 122), dtype=torch.float64, device=dev)
+        scratch = torch.empty(max(lib.imgan_texture_scratch_bytes(H, W, nseg), 8), dtype=torch.uint8,
+                              device=dev)
+        check(lib.imgan_homogeneous_texture(ops._ptr(d_grey), ops._ptr(d_lab), H, W, nseg,
+                                            *[ops._ptr(t) for t in d_tabs], ops._ptr(out),
+                                            ops._ptr(scratch), ops._stream()))
+        o = out.cpu().numpy()
+        feats = []
+        with np.errstate(all="ignore"):
+            for i in range(nseg):
+                sums = o[i, :120].reshape(30, 4)
+                sum_p = sums[:, 0] + 1j * sums[:, 1]
+                sum_q = np.sqrt(sums[:, 2] + 1j * sums[:, 3])                # :355
+                e = np.log10(1 + sum_p)                                     # :353
+                d = np.log10(1 + sum_q)                                     # :356
+                lst = [{'d': np.abs(d[c]), 'e': np.abs(e[c])} for c in range(30)]
+                lst.append(o[i, 120])                                       # :361-364
+                lst.append(o[i, 121])
+                feats.append(lst)
+        return feats
+
+    @staticmethod
+    def radon_feature_extract(image):
+        """mpeg7Descriptors.py:308-365 for one 8-bit grey image."""
+        image = np.asarray(image)
+        if image.ndim != 2 or image.dtype != np.uint8:
+            raise ValueError("radon_feature_extract expects an 8-bit H x W image")
+        none = np.full(image.shape, -1, dtype=np.int32)
+        return MPEG7Descriptors._texture_device(image, none, 1)[0]
+
     def mpeg7_homogeneus_texture(self):
-        raise NotImplementedError("homogeneous texture (mpeg7Descriptors.py:277-365) is a "
-                                  "later row of the build plan (SURVEY.md 8f); not built yet")
+        """mpeg7Descriptors.py:277-284: {segment: [30 x {'d', 'e'}, mean, std]}."""
+        segs, label_map = self._segment_index_map()
+        if not segs:
+            return {}
+        feats = self._texture_device(self.image_gray, label_map, len(segs))
+        return {int(seg): feats[i] for i, seg in enumerate(segs)}
 
 
 EHD_QUANT = [

@@ -241,6 +241,27 @@ int imgan_region_shape(const uint8_t* grey, const int32_t* labels, int H, int W,
                        const double* cos_tab, const double* sin_tab, double r_scale,
                        uint8_t* polar_out, double* art_out, void* scratch, imgan_stream_t stream);
 
+/* ---- homogeneous texture (mpeg7Descriptors.py:277-365, const_data.py) -----------
+ * For every segment s in 0..nseg-1 of `labels` (int32 [H][W], one image): the value image is the
+ * grey level on the segment and where labels < 0, 0 on other segments (segment_generator
+ * :28-38), as float32(g)/255 zero-padded to N x N, N = max(H, W) (:311-319).  Computes the
+ * 329-angle Radon transform through scipy.ndimage.rotate's cubic-spline algorithm (:323-331),
+ * the shifted row FFT (:334-341) and, for the 30 Gabor channels, the complex sums
+ * sum_p = sum ((g * radius) * F)^2 and sum_q = sum (((g * radius) * F)^2 - sum_p)^2 (:351-355).
+ *   rot:      double [329][6] = m00, m01, m10, m11, off0, off1: scipy's rotation matrix
+ *             [[c, s], [-s, c]] (c, s = cosdg / sindg of rad2deg(pi * per / 329)) and offset
+ *   chan:     double [30][4] = centre frequency, 2 * rad_std^2, centre angle (rad), 2 * ang_std^2
+ *   angle_p:  double [329] = 2 pi per / 329;  radius_p: double [N] = linspace(0, 1, N)
+ *   out:      double [nseg][122] = per channel sum_p (re, im), sum_q (re, im); then the mean and
+ *             the population standard deviation of the padded image (:361-362)
+ *   scratch:  imgan_texture_scratch_bytes(H, W, nseg) bytes
+ * All table pointers are device pointers.  nseg = 1 with labels all < 0 = a plain image. */
+size_t imgan_texture_scratch_bytes(int H, int W, int nseg);
+int imgan_homogeneous_texture(const uint8_t* grey, const int32_t* labels, int H, int W, int nseg,
+                              const double* rot, const double* chan, const double* angle_p,
+                              const double* radius_p, double* out, void* scratch,
+                              imgan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
