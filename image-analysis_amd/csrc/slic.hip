@@ -200,6 +200,7 @@ __global__ void slic_fill_kernel(Ws w, int B, int n) {
 // ------------------------------------------------------------------ per-tile candidate lists
 struct AssignParams {
     int B, H, W, S, n, nsub, maxc;
+    long long ntiles;         // B * ntx * nty
     unsigned S2, cw2;         // integer key weights (modes 0, 1); cw2 = 0 in mode 2
     double Sd, cw;            // literal float64 evaluation (mode 2 and exact-key ties)
 };
@@ -354,9 +355,19 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
     uint32_t* acc = reinterpret_cast<uint32_t*>(s_c + maxc);    // [slot][word][lane] partial sums
     uint32_t* tr = acc + maxc * 192;                            // [wave][row][column] transposition
 
-    const int b = blockIdx.z;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2),
+    // so XCD k takes the k-th contiguous eighth of the tile list.  Horizontally adjacent
+    // tiles then run on the same XCD right after each other, and the 128-byte line that their
+    // 192-byte rows share is fetched from HBM once instead of twice.
+    const long long per_xcd = (P.ntiles + 7) / 8;
+    const long long tile = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= P.ntiles) return;
+    const int tiles_per_image = w.ntx * w.nty;
+    const int b = (int)(tile / tiles_per_image);
+    const int trem = (int)(tile - (long long)b * tiles_per_image);
+    const int tby = trem / w.ntx, tbx = trem - tby * w.ntx;
     const int H = P.H, W = P.W, S = P.S, n = P.n, nsub = P.nsub;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * (TH * nsub);
+    const int x0 = tbx * TW, y0 = tby * (TH * nsub);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned long long* sums = w.sums + (size_t)b * n * NFIELD;
@@ -384,8 +395,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
     }
 
     // the tile's sorted candidate record (slic_tiles_kernel), read through the scalar cache
-    const size_t tile = (size_t)b * w.ntx * w.nty + (size_t)blockIdx.y * w.ntx + blockIdx.x;
-    const int8v* recv = w.tiles + tile * TILE_REC;
+    const int8v* recv = w.tiles + (size_t)tile * TILE_REC;
     const int8v AS_CONST* rec = (const int8v AS_CONST*)recv;
     const int m = rec[0][0];
     if (tid < m && m <= maxc) {
@@ -730,6 +740,7 @@ AssignParams make_params(int B, int H, int W, int S, int n, double colour_weight
     P.S2 = (unsigned)(S * S);
     P.cw2 = *mode_out == 2 ? 0u : (unsigned)(colour_weight * colour_weight);
     P.nsub = L.nsub;
+    P.ntiles = (long long)B * L.ntx * L.nty;
     // LDS is sized for about twice the expected number of centres around a tile
     double m_est = (double)(TW + 2 * S) * (TH * L.nsub + 2 * S) / ((double)S * S);
     P.maxc = std::min(MAXC, std::max(16, ((int)(2.0 * m_est) + 4 + 7) / 8 * 8));
@@ -769,7 +780,6 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
     if (int rc = validate("imgan_slic_assign_accumulate", B, H, W, S, n)) return rc;
     IMGAN_REQUIRE(colour_weight > 0.0 && isfinite(colour_weight),
                   "imgan_slic_assign_accumulate: colour_weight must be positive");
-    IMGAN_REQUIRE(B <= 65535, "imgan_slic_assign_accumulate: batch > 65535, split the call");
     Layout L = make_layout(B, H, W, S, n);
     Ws w = bind(workspace, L);
     int mode;
@@ -777,8 +787,8 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
     AssignParams P = make_params(B, H, W, S, n, colour_weight, L, &mode, &rel);
     bool aligned = (W % 4 == 0) && (((uintptr_t)lab & 3) == 0) && (((uintptr_t)labels & 15) == 0);
     size_t lds_bytes = (size_t)P.maxc * (sizeof(int4) + 3 * 64 * sizeof(uint32_t)) + 4 * 256 * 4;
-    dim3 grid((unsigned)L.ntx, (unsigned)L.nty, (unsigned)B);
-    IMGAN_REQUIRE(grid.y <= 65535, "imgan_slic_assign_accumulate: image too tall");
+    IMGAN_REQUIRE((P.ntiles + 7) / 8 * 8 < 0x7fffffffLL, "imgan_slic_assign_accumulate: too many tiles");
+    dim3 grid((unsigned)((P.ntiles + 7) / 8 * 8));
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(M, A, R) hipLaunchKernelGGL((slic_assign_kernel<M, A, R>), grid, dim3(256), lds_bytes, st, lab, labels, w, P)
     if (mode == 0 && rel) { if (aligned) LAUNCH(0, true, true); else LAUNCH(0, false, true); }
