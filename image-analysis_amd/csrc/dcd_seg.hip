@@ -192,14 +192,16 @@ __device__ __forceinline__ void unite16(uint16_t* par, uint32_t a, uint32_t b) {
     }
 }
 
-// FIRST: the small tier visits every segment; the large tier only those left with handled == 0.
+// One segment, start to finish, by the whole workgroup.  FIRST: the small tier visits every
+// segment and puts those that do not fit on the retry list; the large tier works through that
+// list and counts what is still too large (left to the streaming path).
 template <int KM, int CAP, int THREADS, bool FIRST>
-__global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
-    const uint8_t* __restrict__ lab, const int32_t* __restrict__ labels, int H, int W, int nseg,
-    int k, int use_hash, uint32_t seed, float* __restrict__ centres, uint8_t* __restrict__ assign,
-    SegState* __restrict__ seg, unsigned long long* __restrict__ stats,
-    const int* __restrict__ bbox, int* __restrict__ big_count, int max_rounds) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void segment_body(
+    unsigned char* smem, const int b, const int s, const int B, const uint8_t* __restrict__ lab,
+    const int32_t* __restrict__ labels, int H, int W, int nseg, int k, int use_hash, uint32_t seed,
+    float* __restrict__ centres, uint8_t* __restrict__ assign, SegState* __restrict__ seg,
+    unsigned long long* __restrict__ stats, const int* __restrict__ bbox, int* __restrict__ retry,
+    int* __restrict__ big_count, int max_rounds) {
     uint32_t* pix = reinterpret_cast<uint32_t*>(smem);                    // Lab | assign << 24
     uint16_t* pos = reinterpret_cast<uint16_t*>(pix + CAP);               // offset in the bbox
     constexpr bool PACKED = (CAP / 64) * 255 < 65536;
@@ -214,7 +216,6 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
     int& s_n = flags[0];                                                  // the dynamic base 16-B aligned
     int& s_done = flags[1];
 
-    const int b = blockIdx.y, s = blockIdx.x;
     const size_t gs = (size_t)b * nseg + s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef IMGAN_SEG_TIMING
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
         // load under a branch makes the compiler wait for it at the join, which serialises
         // the batch and leaves the gather bound by 8 memory latencies per step).
         const float inv_bw = 1.0f / (float)bw;
-        const size_t last_px = (size_t)gridDim.y * H * W - 1;
+        const size_t last_px = (size_t)B * H * W - 1;
         for (int i0 = 0; i0 < area; i0 += THREADS * 4) {
             int lbl[4], off[4];
             uint32_t pp[4], raw[4], sh[4];
@@ -316,7 +317,10 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
             st.done = 0;
             st.handled = 0;
             seg[gs] = st;
-            if (!FIRST) atomicAdd(big_count, 1);        // left to the streaming path
+            if (FIRST)
+                retry[1 + atomicAdd(&retry[0], 1)] = (int)gs;    // for the large tier
+            else
+                atomicAdd(big_count, 1);                         // left to the streaming path
         }
         return;
     }
@@ -638,6 +642,32 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
     }
 }
 
+template <int KM, int CAP, int THREADS, bool FIRST>
+__global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
+    const uint8_t* __restrict__ lab, const int32_t* __restrict__ labels, int B, int H, int W,
+    int nseg, int k, int use_hash, uint32_t seed, float* __restrict__ centres,
+    uint8_t* __restrict__ assign, SegState* __restrict__ seg, unsigned long long* __restrict__ stats,
+    const int* __restrict__ bbox, int* __restrict__ retry, int* __restrict__ big_count,
+    int max_rounds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (FIRST) {
+        segment_body<KM, CAP, THREADS, true>(smem, blockIdx.y, blockIdx.x, B, lab, labels, H, W, nseg,
+                                             k, use_hash, seed, centres, assign, seg, stats, bbox,
+                                             retry, big_count, max_rounds);
+    } else {
+        // a fixed, small grid walks the retry list (launching one workgroup per segment just to
+        // find most of them done cost more than the segments that needed the retry)
+        const int count = retry[0];
+        for (int e = blockIdx.x; e < count; e += gridDim.x) {
+            const int gs = retry[1 + e];
+            segment_body<KM, CAP, THREADS, false>(smem, gs / nseg, gs % nseg, B, lab, labels, H, W,
+                                                  nseg, k, use_hash, seed, centres, assign, seg,
+                                                  stats, bbox, retry, big_count, max_rounds);
+            __syncthreads();
+        }
+    }
+}
+
 size_t seg_lds_bytes(int km, int cap) {
     const int accw = (cap / 64) * 255 < 65536 ? 3 : 4;
     return (size_t)cap * 6 + (size_t)km * accw * 64 * 4 + (size_t)km * 8 + (size_t)km * 3 * 4 * 2 +
@@ -645,16 +675,16 @@ size_t seg_lds_bytes(int km, int cap) {
 }
 
 template <int KM, int CAP, int THREADS, bool FIRST>
-int launch_tier(dim3 grid, hipStream_t st, const uint8_t* lab, const int32_t* labels, int H, int W,
-                int nseg, int k, int use_hash, uint32_t seed, float* centres, uint8_t* assign,
-                SegState* seg, unsigned long long* stats, const int* bbox, int* n_big,
+int launch_tier(dim3 grid, hipStream_t st, const uint8_t* lab, const int32_t* labels, int B, int H,
+                int W, int nseg, int k, int use_hash, uint32_t seed, float* centres, uint8_t* assign,
+                SegState* seg, unsigned long long* stats, const int* bbox, int* retry, int* n_big,
                 int max_rounds) {
     size_t lds = seg_lds_bytes(KM, CAP);
     auto fn = dcd_segment_kernel<KM, CAP, THREADS, FIRST>;
     IMGAN_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
-    hipLaunchKernelGGL(fn, grid, dim3(THREADS), lds, st, lab, labels, H, W, nseg, k, use_hash, seed,
-                       centres, assign, seg, stats, bbox, n_big, max_rounds);
+    hipLaunchKernelGGL(fn, grid, dim3(THREADS), lds, st, lab, labels, B, H, W, nseg, k, use_hash, seed,
+                       centres, assign, seg, stats, bbox, retry, n_big, max_rounds);
     return 0;
 }
 
@@ -673,7 +703,9 @@ extern "C" int imgan_debug_seg_timing(unsigned long long* out16, int reset) {
 #endif
 
 extern "C" size_t imgan_dcd_bbox_bytes(int B, int nseg) {
-    return (B < 1 || nseg < 1) ? 0 : imgan::align_up((size_t)B * nseg * 4 * 4 + 16, 256);
+    // boxes [B*nseg][4] + the retry list of the large tier {count, ids[B*nseg]}
+    return (B < 1 || nseg < 1) ? 0 : imgan::align_up((size_t)B * nseg * 4 * 4 + 16, 256) +
+                                         imgan::align_up(((size_t)B * nseg + 1) * 4, 256);
 }
 
 extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
@@ -701,12 +733,15 @@ extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int
                        dim3(256), 0, st, bbox, (int)nsegs);
     dim3 gb((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, BBOX_ROWS), (unsigned)B);
     hipLaunchKernelGGL(seg_bbox_kernel, gb, dim3(256), 0, st, labels, H, W, nseg, bbox);
+    int* retry = (int*)((char*)bbox_scratch + imgan::align_up(nsegs * 4 * 4 + 16, 256));
+    IMGAN_HIP(hipMemsetAsync(retry, 0, 4, st));
     dim3 gs((unsigned)nseg, (unsigned)B);
+    dim3 gr((unsigned)std::min<size_t>(nsegs, 2048));
     unsigned long long* stt = (unsigned long long*)stats;
-#define TIER(KM, CAP, THR, FIRST)                                                                  \
-    if (int rc = launch_tier<KM, CAP, THR, FIRST>(gs, st, lab, labels, H, W, nseg, k, use_hash_init, \
-                                                  seed, centres, assign, seg, stt, bbox, n_big_out,  \
-                                                  max_rounds))                                       \
+#define TIER(KM, CAP, THR, FIRST)                                                                   \
+    if (int rc = launch_tier<KM, CAP, THR, FIRST>(FIRST ? gs : gr, st, lab, labels, B, H, W, nseg, k, \
+                                                  use_hash_init, seed, centres, assign, seg, stt,    \
+                                                  bbox, retry, n_big_out, max_rounds))               \
         return rc;
     if (k <= 8) {
         TIER(8, CAP_SMALL, THREADS_SMALL, true)

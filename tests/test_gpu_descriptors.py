@@ -162,8 +162,8 @@ def test_descriptor_methods_on_class():
     assert mp.mpeg7_edge_histogram() == M.ehd_quantise(c, n).tolist()
     h, nw = M.colour_structure_counts(img)
     assert mp.mpeg7_colour_structure() == M.csd_quantise(h, nw).tolist()
-    with pytest.raises(NotImplementedError):
-        mp.mpeg7_region_shape()
+    shape = mp.mpeg7_region_shape()                 # one segment (label 0) covering the frame
+    assert list(shape) == [0] and np.array(shape[0]).shape == (3, 12)
 
 
 def _mix32(h):
