@@ -72,25 +72,52 @@ def measured_traffic(B, H, W, K):
     return int(e["bytes_per_px"] * B * H * W)
 
 
-def cpu_baseline(H, W, K, cw):
-    """The oracle (numpy restatement with the reference's cost structure, slic.py:88-126:
-    per-centre window ops + per-label full-image scans) on a bounded sample."""
+def cpu_baseline(H, W, K, cw, k=8):
+    """The oracle (numpy restatement with the reference's cost structure: per-centre window ops
+    + per-label full-image scans, slic.py:88-126; per-segment Lloyd loops + per-colour
+    connected components, mpeg7Descriptors.py:76-130) on a bounded sample of the same workload:
+    one image, 2 of the 9 SLIC rounds, the whole-image descriptors, dominant colours of 24
+    segments; each part is scaled to its full count."""
     from oracle.synth import voronoi_image
     from oracle.color import bgr2lab_u8
     from oracle.slic_ref import SLICOracle
-    rounds = 2
+    from oracle import mpeg7_std as M
+    from oracle import dcd_ref
+    rounds, nsample = 2, 24
     img = voronoi_image(H, W, K, seed=1234)
     t0 = time.perf_counter()
     lab = bgr2lab_u8(img)
+    t_lab = time.perf_counter() - t0
+    t0 = time.perf_counter()
     o = SLICOracle(lab=lab, num_clusters=K, colour_weight=cw, num_iter=rounds + 1, update="scan")
     o.run()
-    dt = time.perf_counter() - t0
-    # scale the sampled rounds to the full 9-round run (cost is linear in rounds)
-    full = dt * 9.0 / rounds
+    t_slic = (time.perf_counter() - t0) * 9.0 / rounds            # cost is linear in rounds
+    t0 = time.perf_counter()
+    M.colour_layout(img)
+    M.edge_histogram_counts(img)
+    M.colour_structure_counts(img)
+    t_desc = time.perf_counter() - t0
+    labels = o.get_clusters()
+    segs = [s for s in np.unique(labels) if s >= 0]
+    rng = np.random.RandomState(0)
+    t0 = time.perf_counter()
+    done = 0
+    for s in segs[::max(1, len(segs) // nsample)][:nsample]:
+        idx = labels == s
+        pts = lab[idx]
+        if pts.shape[0] < k:
+            continue
+        dcd_ref.dominant_colour(pts, np.transpose(np.nonzero(idx)),
+                                rng.choice(pts.shape[0], k, replace=False), labels.shape)
+        done += 1
+    t_dcd = (time.perf_counter() - t0) * len(segs) / max(done, 1)
+    full = t_lab + t_slic + t_desc + t_dcd
     return {"value": round(H * W / 1e6 / full, 4), "unit": "megapixels/sec", "cores": 1,
             "kind": "port",
-            "sample": "1 image %dx%d K=%d: numpy oracle Lab + %d of 9 SLIC rounds (%.1f s), "
-                      "scaled to 9 rounds; SLIC stage only" % (W, H, K, rounds, dt)}
+            "sample": "1 image %dx%d K=%d, numpy oracle, 1 thread: Lab %.1f s + SLIC %.1f s (2 of 9 "
+                      "rounds timed, scaled) + CLD/EHD/CSD %.1f s + dominant colours %.1f s (%d of "
+                      "%d segments timed, scaled) = %.0f s for the whole path" %
+                      (W, H, K, t_lab, t_slic, t_desc, t_dcd, done, len(segs), full)}
 
 
 def main():
@@ -113,7 +140,8 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     B, H, W, K = args.batch, args.height, args.width, args.clusters
     cw, num_iter = 15, 10
