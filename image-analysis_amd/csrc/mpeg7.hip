@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
                                                   int K, int nwx, int nwy, int nbins,
                                                   int32_t* __restrict__ out, HmmdTab T) {
     __shared__ uint8_t cell[CS_PH * CS_PW];
+    __shared__ uint32_t runs[CS_PH * 8 * CS_W];     // [patch row][mask word][column]
     __shared__ uint32_t hist[256];
     const int b = blockIdx.z;
     const int u0 = blockIdx.x * CS_W, v0 = blockIdx.y * CS_H;
@@ -347,6 +348,23 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
         cell[i] = c;
     }
     __syncthreads();
+    // The 8 x 8 structuring element is separable for "which colours occur": first the set of
+    // colours (a 256-bit mask, 8 words) of every horizontal run of 8 cells, once per patch row
+    // and column, then each window ORs the 8 runs below its origin.
+    for (int i = threadIdx.x; i < CS_PH * CS_W; i += 256) {
+        const int pv = i >> 5, pu = i & 31;
+        uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int du = 0; du < 8; ++du) {
+            const uint32_t c = cell[pv * CS_PW + pu + du];
+            const uint32_t bit = 1u << (c & 31u), wsel = c >> 5;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) r[w] |= (wsel == (uint32_t)w) ? bit : 0u;
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) runs[(pv * 8 + w) * CS_W + pu] = r[w];   // lanes along pu
+    }
+    __syncthreads();
     const int tu = threadIdx.x & 31, tv = threadIdx.x >> 5;
     const bool valid = (u0 + tu < nwx) && (v0 + tv < nwy);
     uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -354,12 +372,7 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
 #pragma unroll
         for (int dv = 0; dv < 8; ++dv)
 #pragma unroll
-            for (int du = 0; du < 8; ++du) {
-                uint32_t c = cell[(tv + dv) * CS_PW + tu + du];
-                uint32_t bit = 1u << (c & 31u), wsel = c >> 5;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) m[w] |= (wsel == (uint32_t)w) ? bit : 0u;
-            }
+            for (int w = 0; w < 8; ++w) m[w] |= runs[((tv + dv) * 8 + w) * CS_W + tu];
     }
     // every colour present in a window counts once: count lanes per bit, one add per wave
     const int lane = threadIdx.x & 63;
