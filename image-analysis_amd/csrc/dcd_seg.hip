@@ -212,7 +212,8 @@ __device__ __forceinline__ void segment_body(
     float* cen = reinterpret_cast<float*>(slots + KM);                   // [KM][3]
     float* old = cen + KM * 3;                                            // [KM][3]
     uint32_t* red = reinterpret_cast<uint32_t*>(old + KM * 3);           // [KM][4] count, sums
-    int* flags = reinterpret_cast<int*>(red + KM * 4);                    // no static LDS: keeps
+    float* sbuf = reinterpret_cast<float*>(red + KM * 4);                 // [3][KM] shifts per cluster
+    int* flags = reinterpret_cast<int*>(sbuf + KM * 3);                   // no static LDS: keeps
     int& s_n = flags[0];                                                  // the dynamic base 16-B aligned
     int& s_done = flags[1];
 
@@ -474,12 +475,30 @@ __device__ __forceinline__ void segment_body(
                 a1 = fabsf(__fsub_rn(c1, old[KM + lane]));
                 a2 = fabsf(__fsub_rn(c2, old[2 * KM + lane]));
             }
-            float sh0 = 0.f, sh1 = 0.f, sh2 = 0.f;      // float32 sums in cluster order (:102)
-            for (int j = 0; j < k; ++j) {
-                sh0 = __fadd_rn(sh0, __shfl(a0, j));
-                sh1 = __fadd_rn(sh1, __shfl(a1, j));
-                sh2 = __fadd_rn(sh2, __shfl(a2, j));
+            // float32 sums in cluster order (:102).  The shifts go through LDS and every lane
+            // adds them up itself: all the reads are issued at once (one round trip) where a
+            // chain of cross-lane shuffles costs one round trip per term.
+            if (lane < KM) {
+                sbuf[lane] = a0;
+                sbuf[KM + lane] = a1;
+                sbuf[2 * KM + lane] = a2;
             }
+            __builtin_amdgcn_wave_barrier();            // same wave: LDS operations are in order
+            float t0[KM], t1[KM], t2[KM];
+#pragma unroll
+            for (int j = 0; j < KM; ++j) {
+                t0[j] = sbuf[j];
+                t1[j] = sbuf[KM + j];
+                t2[j] = sbuf[2 * KM + j];
+            }
+            float sh0 = 0.f, sh1 = 0.f, sh2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < KM; ++j)
+                if (j < k) {
+                    sh0 = __fadd_rn(sh0, t0[j]);
+                    sh1 = __fadd_rn(sh1, t1[j]);
+                    sh2 = __fadd_rn(sh2, t2[j]);
+                }
             const double cent_sum = ((double)sh0 + (double)sh1) + (double)sh2;
             rounds += 1;
             const bool stop = fabs(old_sum - cent_sum) < 0.1 || rounds >= max_rounds;
@@ -671,7 +690,7 @@ __global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
 size_t seg_lds_bytes(int km, int cap) {
     const int accw = (cap / 64) * 255 < 65536 ? 3 : 4;
     return (size_t)cap * 6 + (size_t)km * accw * 64 * 4 + (size_t)km * 8 + (size_t)km * 3 * 4 * 2 +
-           (size_t)km * 4 * 4 + 16;
+           (size_t)km * 4 * 4 + (size_t)km * 3 * 4 + 16;
 }
 
 template <int KM, int CAP, int THREADS, bool FIRST>
