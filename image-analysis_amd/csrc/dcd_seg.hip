@@ -38,6 +38,13 @@ __device__ unsigned long long seg_timing[16];
 #endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// median of three unsigned words in one instruction (the compiler has no builtin for it)
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;   // one global_load_dword at any address
 
 constexpr int CAP_SMALL = 11776, THREADS_SMALL = 512;       // 6 B of LDS per pixel
@@ -356,7 +363,10 @@ __device__ __forceinline__ void segment_body(
     if (tid == 0) s_done = 0;
     double old_sum = 0.0;              // only lane 0 of wave 0 uses its copy
     int rounds = 0;
-    const float NEAR = 1.0f - 9.5367431640625e-07f;       // 1 - 2^-20
+    // a q within 2^-17 of the smallest one replays the literal rule: 2^-20 for the sqrt rounding
+    // the fast loop skips, up to 2^-19 for the mantissa bits that carry the cluster index
+    const float NEAR = 1.0f - 7.62939453125e-06f;          // 1 - 2^-17
+    constexpr uint32_t IDXM = KM - 1;
 
     // ---- Lloyd rounds (:85-107).  Two barriers per round: all waves assign, then the first
     // wave alone folds the lane-private sums (clearing them for the next round), moves the
@@ -380,21 +390,25 @@ __device__ __forceinline__ void segment_body(
             // first minimum of sqrt_rn(q).  The first minimum of q itself is the same cluster
             // unless another q lies within a few ulp of the smallest one, so the fast loop
             // tracks the two smallest q and only a near tie replays the literal rule.
+            // q >= +0, so the float order is the order of the bit patterns: the cluster index
+            // rides in the low mantissa bits (IDXM + 1 ulp of slack, covered by NEAR) and one
+            // unsigned min / med3 per cluster tracks the smallest and second smallest q.
             const f32x2 F0 = {f0, f0}, F1 = {f1, f1}, F2 = {f2, f2};
-            float best = __builtin_inff(), second = __builtin_inff();
-            int bi = 0;
+            uint32_t best = 0xffffffffu, second = 0xffffffffu;
 #pragma unroll
             for (int jj = 0; jj < KM / 2; ++jj) {
                 const f32x2 d0 = F0 - c0[jj], d1 = F1 - c1[jj], d2 = F2 - c2[jj];
                 const f32x2 q = (d0 * d0 + d1 * d1) + d2 * d2;
-                second = __builtin_amdgcn_fmed3f(q.x, best, second);
-                bi = q.x < best ? 2 * jj : bi;
-                best = fminf(best, q.x);
-                second = __builtin_amdgcn_fmed3f(q.y, best, second);
-                bi = q.y < best ? 2 * jj + 1 : bi;
-                best = fminf(best, q.y);
+                const uint32_t kx = (__float_as_uint(q.x) & ~IDXM) | (uint32_t)(2 * jj);
+                const uint32_t ky = (__float_as_uint(q.y) & ~IDXM) | (uint32_t)(2 * jj + 1);
+                second = umed3(kx, best, second);
+                best = min(best, kx);
+                second = umed3(ky, best, second);
+                best = min(best, ky);
             }
-            if (__builtin_expect(__fmul_rn(second, NEAR) < best, 0)) {
+            int bi = (int)(best & IDXM);
+            if (__builtin_expect(__fmul_rn(__uint_as_float(second & ~IDXM), NEAR) <
+                                 __uint_as_float(best & ~IDXM), 0)) {
                 float bs = __builtin_inff();
                 bi = 0;
                 for (int j = 0; j < k; ++j) {
