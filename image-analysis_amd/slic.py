@@ -32,18 +32,24 @@ class SLICSuperPixel(object):
         self.num_iter = num_iter
         self.num_clusters = num_clusters
         self.colour_weight = colour_weight
-        self._plan = ops.SlicPlan(1, height, width, num_clusters, step)
-        self.step = self._plan.S                                      # slic.py:29-33
+        self.step, nx, ny = ops.slic_grid(height, width, num_clusters, step)   # slic.py:29-33
+        # an empty seed grid (step larger than the image) is not an error in the reference:
+        # its loops simply do nothing and every pixel stays -1
+        self._plan = ops.SlicPlan(1, height, width, num_clusters, step) if nx * ny else None
         self._dev_labels = None
 
     def _pull_centres(self):
+        if self._plan is None:
+            self.centers, self.center_counts = [], []
+            return
         c = self._plan.centres[0].cpu().numpy()
         self.centers = [[int(v) for v in row] for row in c]
         self.center_counts = [0.0] * len(self.centers)
 
     def init_clusters(self):
         """slic.py:35-54."""
-        self._plan.init(self._dev_lab)
+        if self._plan is not None:
+            self._plan.init(self._dev_lab)
         self._pull_centres()
 
     @staticmethod
@@ -63,6 +69,10 @@ class SLICSuperPixel(object):
 
     def run(self):
         """slic.py:78-127."""
+        if self._plan is None:
+            self._pull_centres()
+            self.clusters = np.full(self.image.shape[:2], -1.0)
+            return
         labels, _ = self._plan.run(self._dev_lab, self.colour_weight, self.num_iter)
         self._dev_labels = labels[0]
         self._pull_centres()
