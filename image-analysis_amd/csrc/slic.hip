@@ -9,7 +9,7 @@
 //
 // Data flow per round (all state in the caller's workspace, nothing allocated here):
 //   bin:     centres -> S x S cell lists (count / scan / fill) + colour at the centre position
-//   assign:  one workgroup per 64 x 16 pixel tile.  The centres whose window can reach the
+//   assign:  one workgroup per 64 x 32 / 64 x 64 pixel tile.  The centres whose window can reach the
 //            tile are gathered into LDS (sorted by index, so "first strictly smaller wins"
 //            is exactly the reference's sequential sweep), every lane evaluates its 4 pixels
 //            against them with an exact integer key
@@ -29,8 +29,8 @@
 namespace {
 
 constexpr int TW = 64;      // tile width  (16 lanes x 4 pixels)
-constexpr int TH = 16;      // tile height (4 waves x 4 rows)
-constexpr int NSUBMAX = 4; // bands of 16 rows per tile (pixels of all bands prefetched)
+constexpr int TILE_H_MAX = 64;   // tallest tile: 2 bands x 4 waves x 8 rows
+constexpr int NSUBMAX = 2;      // bands per tile (pixels of all bands prefetched)
 constexpr int MAXC = 48;    // most centres per tile the LDS fast path can be sized for
 constexpr int NFIELD = 6;   // sum L, a, b, x, y, count
 constexpr int TILE_REC = 1 + MAXC;   // 32-byte records per tile: header {m} + sorted candidates
@@ -40,13 +40,16 @@ typedef int int8v __attribute__((ext_vector_type(8)));
 
 struct Layout {
     int ncx, ncy, ncell;
-    int nsub, ntx, nty;          // assignment tiles: 64 x (16*nsub) pixels
+    int nsub, tile_h, ntx, nty;  // assignment tiles: 64 x tile_h pixels (nsub bands)
     size_t off_count, off_start, off_fill, off_scand, off_cand, off_sums, off_tiles, total;
 };
 
-// taller tiles amortise the per-tile prologue / flush; small steps keep them short so that the
-// number of centres reaching a tile stays below MAXC
-int choose_nsub(int S) { return S >= 48 ? 4 : (S >= 28 ? 2 : 1); }
+// A lane owns `rows` vertically adjacent pixels of its column: everything per candidate that is
+// not per pixel (the entry, the column test, the x part of the key) is paid once for them.  A
+// band is 4 waves x rows tall; taller tiles amortise the per-tile prologue / flush; small steps
+// keep tiles short so that the number of centres reaching a tile stays below MAXC.
+int choose_rows(int S) { return S >= 28 ? 8 : 4; }
+int choose_nsub(int S) { return S >= 48 ? 2 : 1; }
 
 Layout make_layout(int B, int H, int W, int S, int n) {
     Layout L;
@@ -66,8 +69,9 @@ Layout make_layout(int B, int H, int W, int S, int n) {
     L.off_cand = take((size_t)B * n * 16);
     L.off_sums = take((size_t)B * n * NFIELD * 8);
     L.nsub = choose_nsub(S);
+    L.tile_h = 4 * choose_rows(S) * L.nsub;
     L.ntx = (W - 1 + TW - 1) / TW;
-    L.nty = (H - 1 + TH * L.nsub - 1) / (TH * L.nsub);
+    L.nty = (H - 1 + L.tile_h - 1) / L.tile_h;
     if (L.ntx < 1) L.ntx = 1;
     if (L.nty < 1) L.nty = 1;
     L.off_tiles = take((size_t)B * L.ntx * L.nty * TILE_REC * sizeof(int8v));
@@ -84,7 +88,7 @@ struct Ws {
     unsigned long long* sums;
     int8v* tiles;           // [B][nty][ntx][TILE_REC]: {m,..}, then the candidates by idx
     int ncx, ncy, ncell;
-    int nsub, ntx, nty;
+    int nsub, tile_h, ntx, nty;
 };
 
 Ws bind(void* ws, const Layout& L) {
@@ -101,6 +105,7 @@ Ws bind(void* ws, const Layout& L) {
     w.ncell = L.ncell;
     w.tiles = (int8v*)(p + L.off_tiles);
     w.nsub = L.nsub;
+    w.tile_h = L.tile_h;
     w.ntx = L.ntx;
     w.nty = L.nty;
     return w;
@@ -227,8 +232,8 @@ __global__ __launch_bounds__(256) void slic_tiles_kernel(Ws w, AssignParams P) {
         const int ti = (int)(t - (long long)b * ntiles);
         const int ty = ti / w.ntx, tx = ti - ty * w.ntx;
         x0 = tx * TW;
-        y0 = ty * (TH * w.nsub);
-        const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + TH * w.nsub - 1, H - 2);
+        y0 = ty * w.tile_h;
+        const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + w.tile_h - 1, H - 2);
         // centres that can cover a pixel of the tile: cx in [x0-S+1, x1+S], cy likewise
         const int cxl = max(x0 - S + 1, 0) / S, cxh = min((x1 + S) / S, w.ncx - 1);
         const int cyl = max(y0 - S + 1, 0) / S, cyh = min((y1 + S) / S, w.ncy - 1);
@@ -331,11 +336,12 @@ __device__ __forceinline__ void flush_pixel_global(unsigned long long* sums, int
 // MODE 0: 32-bit key with the dot4 expansion (fast path); 1: u64; 2: literal float64.
 // REL (mode 0 only): the key is kept relative to its per-pixel constant (see below).
 //
-// One workgroup = a 64 x (16*nsub) pixel tile; wave w takes rows 4w..4w+3 of every 16-row
-// band.  Inside a wave LANE = COLUMN and the four pixels of a lane are the four ROWS, so for a
-// given candidate everything that depends on the row is the same for all 64 lanes and lives
-// in scalar registers (the row-in-window tests, the y part of the key); per lane and
-// candidate only the column test and the x part are left.
+// One workgroup = a 64 x tile_h pixel tile made of nsub bands of 4 x R rows; wave w takes rows
+// R w .. R w + R - 1 of every band.  Inside a wave LANE = COLUMN and the R pixels of a lane are
+// R consecutive ROWS, so for a given candidate everything that depends on the row is the same
+// for all 64 lanes and lives in scalar registers (the row-in-window tests, the y part of the
+// key); per lane and candidate only the column test and the x part are left, paid once for the
+// lane's R pixels.
 //
 // Mode 0 key.  With p, c the Lab bytes of pixel and centre, (x, y) / (cx', cy') tile relative:
 //     key = S^2 |p - c|^2 + cw^2 ((x - cx')^2 + (y - cy')^2)
@@ -343,7 +349,7 @@ __device__ __forceinline__ void flush_pixel_global(unsigned long long* sums, int
 // T is the same for every candidate of a pixel, so it cannot change which one wins: REL drops
 // it and compares the signed remainder (needs |key| < 2^31, checked on the host); otherwise
 // T is added and the comparison is unsigned below 2^32.  p . c is one v_dot4_u32_u8.
-template <int MODE, bool ALIGNED, bool REL>
+template <int MODE, bool ALIGNED, bool REL, int R>
 __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restrict__ lab,
                                                           int32_t* __restrict__ labels, Ws w,
                                                           AssignParams P) {
@@ -367,7 +373,8 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
     const int trem = (int)(tile - (long long)b * tiles_per_image);
     const int tby = trem / w.ntx, tbx = trem - tby * w.ntx;
     const int H = P.H, W = P.W, S = P.S, n = P.n, nsub = P.nsub;
-    const int x0 = tbx * TW, y0 = tby * (TH * nsub);
+    constexpr int BAND = 4 * R;                           // rows per band: 4 waves x R rows
+    const int x0 = tbx * TW, y0 = tby * w.tile_h;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned long long* sums = w.sums + (size_t)b * n * NFIELD;
@@ -382,16 +389,19 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
         px[2] = __builtin_amdgcn_perm(v.c, v.b, 0x0c040302u);
         px[3] = v.c >> 8;
     };
-    Dword3 raw[NSUBMAX];
+    Dword3 raw[NSUBMAX][R / 4];
     if (ALIGNED) {
         const int xl = x0 + (lane & 15) * 4;
 #pragma unroll
-        for (int sub = 0; sub < NSUBMAX; ++sub) {
-            raw[sub].a = raw[sub].b = raw[sub].c = 0;
-            const int yy = y0 + sub * TH + wave * 4 + (lane >> 4);
-            if (sub < nsub && yy < H - 1 && xl < W - 1)
-                raw[sub] = *reinterpret_cast<const Dword3*>(lab + (((size_t)b * H + yy) * W + xl) * 3);
-        }
+        for (int sub = 0; sub < NSUBMAX; ++sub)
+#pragma unroll
+            for (int g = 0; g < R / 4; ++g) {
+                raw[sub][g].a = raw[sub][g].b = raw[sub][g].c = 0;
+                const int yy = y0 + sub * BAND + wave * R + g * 4 + (lane >> 4);
+                if (sub < nsub && yy < H - 1 && xl < W - 1)
+                    raw[sub][g] =
+                        *reinterpret_cast<const Dword3*>(lab + (((size_t)b * H + yy) * W + xl) * 3);
+            }
     }
 
     // the tile's sorted candidate record (slic_tiles_kernel), read through the scalar cache
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
     if (m > maxc) {
         // ---- slow path: too many centres around this tile (degenerate inputs).  Every lane
         // walks the cell lists itself for one pixel at a time and flushes with global atomics.
-        const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + TH * nsub - 1, H - 2);
+        const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + w.tile_h - 1, H - 2);
         const int4* scand = w.scand + (size_t)b * n;
         const int* start = w.start + (size_t)b * (w.ncell + 1);
         const int cxl = max(x0 - S + 1, 0) / S, cxh = min((x1 + S) / S, w.ncx - 1);
@@ -461,29 +471,32 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
 
     const int twoS = 2 * S;
     const int nS2x2 = -2 * (int)P.S2;
-    uint32_t* trw = tr + wave * 256;
+    uint32_t* trw = tr + wave * (R * 64);
     for (int sub = 0; sub < nsub; ++sub) {
-        const int wy0 = sub * TH + wave * 4;             // tile relative first row of this wave
+        const int wy0 = sub * BAND + wave * R;           // tile relative first row of this wave
         if (y0 + wy0 >= H - 1) continue;                 // whole wave below the image
-        uint32_t px[4];
+        uint32_t px[R];
         if (ALIGNED) {
-            Dword3 v = raw[0];
-#pragma unroll
-            for (int k = 1; k < NSUBMAX; ++k)
-                if (sub == k) v = raw[k];
-            uint32_t q[4];
-            unpack(v, q);
             // LDS operations of one wave complete in order: no barrier between the row-major
             // store and the column reads, nor before the next band overwrites the patch
-            *reinterpret_cast<uint4*>(trw + (lane >> 4) * 64 + (lane & 15) * 4) =
-                make_uint4(q[0], q[1], q[2], q[3]);
+#pragma unroll
+            for (int g = 0; g < R / 4; ++g) {
+                Dword3 v = raw[0][g];
+#pragma unroll
+                for (int k = 1; k < NSUBMAX; ++k)
+                    if (sub == k) v = raw[k][g];
+                uint32_t q[4];
+                unpack(v, q);
+                *reinterpret_cast<uint4*>(trw + (g * 4 + (lane >> 4)) * 64 + (lane & 15) * 4) =
+                    make_uint4(q[0], q[1], q[2], q[3]);
+            }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) px[j] = trw[j * 64 + lane];
+            for (int j = 0; j < R; ++j) px[j] = trw[j * 64 + lane];
             __builtin_amdgcn_wave_barrier();
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < R; ++j) {
                 px[j] = 0;
                 const int yy = y0 + wy0 + j;
                 if (yy < H - 1 && colok) {
@@ -493,14 +506,16 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
             }
         }
 
-        int slot[4] = {-1, -1, -1, -1};
+        int slot[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) slot[j] = -1;
         unsigned tied = 0;                  // bit j: the best key of pixel j may have been met again
         if (MODE == 0) {
-            int best[4];
-            uint32_t T[4];
-            unsigned long long tie[4];      // lane masks (wave uniform values: scalar registers)
+            int best[R];
+            uint32_t T[R];
+            unsigned long long tie[R];      // lane masks (wave uniform values: scalar registers)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < R; ++j) {
                 best[j] = REL ? 0x7fffffff : -1;
                 tie[j] = 0ull;
                 T[j] = 0;
@@ -520,7 +535,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
                 const int q0 = c[4] - c[6] * wy0;
                 const uint32_t cl = (uint32_t)c[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < R; ++j) {
                     const unsigned long long inm =
                         (all_rows || (unsigned)(t0 + j) < (unsigned)twoS) ? inxm : 0ull;
                     const int pc = (int)__builtin_amdgcn_udot4(px[j], cl, 0u, false);
@@ -539,22 +554,22 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
             for (int s = 0; s < m; ++s) {
                 const int8v c = rec[1 + s];
                 const int t0 = wy0 - c[1] + S;           // row j is inside iff 0 <= t0 + j < 2S
-                if (t0 + 3 < 0 || t0 >= twoS) continue;  // no row of this wave inside
-                if (t0 >= 0 && t0 + 3 < twoS)
+                if (t0 + (R - 1) < 0 || t0 >= twoS) continue;  // no row of this wave inside
+                if (t0 >= 0 && t0 + (R - 1) < twoS)
                     eval(s, c, t0, true);
                 else
                     eval(s, c, t0, false);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < R; ++j)
                 tied |= (((tie[j] >> lane) & 1ull) != 0ull && slot[j] >= 0) ? (1u << j) : 0u;
         } else {
-            typename KeyT<MODE>::type best[4];
+            typename KeyT<MODE>::type best[R];
             for (int s = 0; s < m; ++s) {
                 const int4 c0 = s_c[s];
                 const bool inx = (unsigned)(xr - c0.x + S) < (unsigned)twoS;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < R; ++j) {
                     bool in = inx && ((unsigned)(wy0 + j - c0.y + S) < (unsigned)twoS);
                     if (!in) continue;
                     auto key = generic_key<MODE>(px[j], xr, wy0 + j, (uint32_t)c0.z, c0.x, c0.y, P);
@@ -572,7 +587,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
         // centre order with a strict '<', so replay the candidates that cover the pixel.
         if (tied) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < R; ++j) {
                 if (!((tied >> j) & 1u)) continue;
                 const int yr = wy0 + j;
                 const int4 cb = s_c[slot[j]];
@@ -598,7 +613,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
 
         // ---- labels out + accumulate (a row of 64 labels per store instruction)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < R; ++j) {
             const int yr = wy0 + j, y = y0 + yr;
             if (!(y < H - 1 && colok)) continue;
             const size_t li = ((size_t)b * H + y) * W + x;
@@ -619,7 +634,7 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
 
     // ---- reduce the 64 lane-private copies and flush: 16 lanes per slot = 4 lanes for each of
     // its 3 packed rows (L|a, b|count, x'|y'), 16 copies per lane.  A copy holds at most
-    // 4 waves x 4 bands x 4 rows = 64 pixels, so its 16-bit halves cannot overflow
+    // 4 waves x nsub bands x R rows = tile height <= 64 pixels, so its 16-bit halves cannot overflow
     // (64 * 255 < 65536); the halves are widened before they are summed.
     for (int s0 = 0; s0 < m; s0 += 16) {
         const int s = s0 + (tid >> 4), r = (tid >> 2) & 3, q = tid & 3;
@@ -673,9 +688,9 @@ int key_mode(int S, double cw, bool* rel) {
     double r = rint(cw);
     if (r != cw || cw < 1.0 || cw > 4096.0) return 2;
     double cw2 = cw * cw, S2 = (double)S * S;
-    double span = (double)(TW + S) * (TW + S) + (double)(4 * TH + S) * (4 * TH + S);
+    double span = (double)(TW + S) * (TW + S) + (double)(TILE_H_MAX + S) * (TILE_H_MAX + S);
     bool fits32 = S2 * 195075.0 + cw2 * span < 4294967295.0 &&
-                  2.0 * cw2 * (4 * TH + TW + S) < 8388608.0 && 2.0 * S2 < 8388608.0;
+                  2.0 * cw2 * (TILE_H_MAX + TW + S) < 8388608.0 && 2.0 * S2 < 8388608.0;
     *rel = fits32 && S2 * 195075.0 + cw2 * span < 2147483647.0;
     return fits32 ? 0 : 1;
 }
@@ -742,7 +757,7 @@ AssignParams make_params(int B, int H, int W, int S, int n, double colour_weight
     P.nsub = L.nsub;
     P.ntiles = (long long)B * L.ntx * L.nty;
     // LDS is sized for about twice the expected number of centres around a tile
-    double m_est = (double)(TW + 2 * S) * (TH * L.nsub + 2 * S) / ((double)S * S);
+    double m_est = (double)(TW + 2 * S) * (L.tile_h + 2 * S) / ((double)S * S);
     P.maxc = std::min(MAXC, std::max(16, ((int)(2.0 * m_est) + 4 + 7) / 8 * 8));
     return P;
 }
@@ -786,16 +801,20 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
     bool rel;
     AssignParams P = make_params(B, H, W, S, n, colour_weight, L, &mode, &rel);
     bool aligned = (W % 4 == 0) && (((uintptr_t)lab & 3) == 0) && (((uintptr_t)labels & 15) == 0);
-    size_t lds_bytes = (size_t)P.maxc * (sizeof(int4) + 3 * 64 * sizeof(uint32_t)) + 4 * 256 * 4;
+    const int rows = choose_rows(S);
+    size_t lds_bytes = (size_t)P.maxc * (sizeof(int4) + 3 * 64 * sizeof(uint32_t)) +
+                       (size_t)4 * rows * 64 * 4;
     IMGAN_REQUIRE((P.ntiles + 7) / 8 * 8 < 0x7fffffffLL, "imgan_slic_assign_accumulate: too many tiles");
     dim3 grid((unsigned)((P.ntiles + 7) / 8 * 8));
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(M, A, R) hipLaunchKernelGGL((slic_assign_kernel<M, A, R>), grid, dim3(256), lds_bytes, st, lab, labels, w, P)
+#define LAUNCH1(M, A, E, RR) hipLaunchKernelGGL((slic_assign_kernel<M, A, E, RR>), grid, dim3(256), lds_bytes, st, lab, labels, w, P)
+#define LAUNCH(M, A, E) do { if (rows == 8) LAUNCH1(M, A, E, 8); else LAUNCH1(M, A, E, 4); } while (0)
     if (mode == 0 && rel) { if (aligned) LAUNCH(0, true, true); else LAUNCH(0, false, true); }
     else if (mode == 0) { if (aligned) LAUNCH(0, true, false); else LAUNCH(0, false, false); }
     else if (mode == 1) { if (aligned) LAUNCH(1, true, false); else LAUNCH(1, false, false); }
     else { if (aligned) LAUNCH(2, true, false); else LAUNCH(2, false, false); }
 #undef LAUNCH
+#undef LAUNCH1
     return imgan::check_launch("slic_assign_kernel");
 }
 
