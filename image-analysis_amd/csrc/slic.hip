@@ -392,15 +392,18 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
     Dword3 raw[NSUBMAX][R / 4];
     if (ALIGNED) {
         const int xl = x0 + (lane & 15) * 4;
+        const int yl = y0 + wave * R + (lane >> 4);
+        // one 64-bit address per lane, stepped by whole rows (uniform offsets)
+        const uint8_t* src = lab + (((size_t)b * H + yl) * W + xl) * 3;
+        const size_t row3 = (size_t)W * 3;
 #pragma unroll
         for (int sub = 0; sub < NSUBMAX; ++sub)
 #pragma unroll
             for (int g = 0; g < R / 4; ++g) {
                 raw[sub][g].a = raw[sub][g].b = raw[sub][g].c = 0;
-                const int yy = y0 + sub * BAND + wave * R + g * 4 + (lane >> 4);
-                if (sub < nsub && yy < H - 1 && xl < W - 1)
-                    raw[sub][g] =
-                        *reinterpret_cast<const Dword3*>(lab + (((size_t)b * H + yy) * W + xl) * 3);
+                const int dy = sub * BAND + g * 4;
+                if (sub < nsub && yl + dy < H - 1 && xl < W - 1)
+                    raw[sub][g] = *reinterpret_cast<const Dword3*>(src + (size_t)dy * row3);
             }
     }
 
@@ -560,9 +563,14 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
                 else
                     eval(s, c, t0, false);
             }
+            unsigned long long any_tie = 0ull;
 #pragma unroll
-            for (int j = 0; j < R; ++j)
-                tied |= (((tie[j] >> lane) & 1ull) != 0ull && slot[j] >= 0) ? (1u << j) : 0u;
+            for (int j = 0; j < R; ++j) any_tie |= tie[j];
+            if (any_tie != 0ull) {                       // wave uniform, rarely taken
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    tied |= (((tie[j] >> lane) & 1ull) != 0ull && slot[j] >= 0) ? (1u << j) : 0u;
+            }
         } else {
             typename KeyT<MODE>::type best[R];
             for (int s = 0; s < m; ++s) {
@@ -611,21 +619,23 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
             }
         }
 
-        // ---- labels out + accumulate (a row of 64 labels per store instruction)
+        // ---- labels out + accumulate (a row of 64 labels per store instruction).  The 64-bit
+        // address is formed once per band and stepped by a row; LDS offsets use 24-bit
+        // multiplies (the 32-bit multiply-add of this chip is a quarter-rate 64-bit one).
+        int32_t* lrow = labels + ((size_t)b * H + (y0 + wy0)) * W + x;
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
+        for (int j = 0; j < R; ++j, lrow += W) {
             const int yr = wy0 + j, y = y0 + yr;
             if (!(y < H - 1 && colok)) continue;
-            const size_t li = ((size_t)b * H + y) * W + x;
             if (slot[j] >= 0) {
-                labels[li] = s_c[slot[j]].w;
+                *lrow = s_c[slot[j]].w;
                 const uint32_t p = px[j];
-                uint32_t* a = acc + slot[j] * 192 + lane;
+                uint32_t* a = acc + (__mul24(slot[j], 192) + lane);
                 atomicAdd(a, (p & 0xffu) | ((p & 0xff00u) << 8));
                 atomicAdd(a + 64, ((p >> 16) & 0xffu) | 0x10000u);
                 atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)yr << 16));
             } else {
-                const int old = labels[li];           // not covered this round: keeps its label
+                const int old = *lrow;                // not covered this round: keeps its label
                 if (old >= 0) flush_pixel_global(sums, old, px[j], x, y);
             }
         }
