@@ -261,6 +261,7 @@ __device__ __forceinline__ void segment_body(
         // the batch and leaves the gather bound by 8 memory latencies per step).
         const float inv_bw = 1.0f / (float)bw;
         const size_t last_px = (size_t)B * H * W - 1;
+        const bool kpow2 = (k & (k - 1)) == 0;
         for (int i0 = 0; i0 < area; i0 += THREADS * 4) {
             int lbl[4], off[4];
             uint32_t pp[4], raw[4], sh[4];
@@ -270,16 +271,18 @@ __device__ __forceinline__ void segment_body(
                 off[u] = i;
                 const int ic = i < area ? i : area - 1;
                 int yy = (int)((float)ic * inv_bw);
-                int xx = ic - yy * bw;
+                // 24-bit multiplies: box cells < 2^16, rows < 2^16, W < 2^23 (checked by the host);
+                // the 32-bit multiply of this chip runs at a quarter of their rate
+                int xx = ic - __mul24(yy, bw);
                 yy += (xx >= bw) - (xx < 0);            // the float quotient can be off by one
-                xx = ic - yy * bw;
-                pp[u] = (uint32_t)((ymin + yy) * W + xmin + xx);
+                xx = ic - __mul24(yy, bw);
+                pp[u] = (uint32_t)(__mul24(ymin + yy, W) + xmin + xx);
                 lbl[u] = labels[img + pp[u]];
                 // the three Lab bytes with one (unaligned) dword load; the very last pixel of
                 // the batch is read one byte early so that the load stays inside the buffer
                 const size_t gp = img + pp[u];
                 sh[u] = gp == last_px ? 1u : 0u;
-                raw[u] = *reinterpret_cast<const u32_unaligned*>(lab + gp * 3 - sh[u]);
+                raw[u] = *reinterpret_cast<const u32_unaligned*>(lab + ((gp << 1) + gp) - sh[u]);
             }
             uint32_t v[4];
             int slot[4];
@@ -310,7 +313,7 @@ __device__ __forceinline__ void segment_body(
                     const uint32_t h = mix32(pp[u] * 0x9e3779b1u + seed);
                     const unsigned long long key =
                         ((unsigned long long)h << 32) | (unsigned long long)pp[u];
-                    unsigned long long* sl = &slots[h % (uint32_t)k];
+                    unsigned long long* sl = &slots[kpow2 ? (h & (uint32_t)(k - 1)) : h % (uint32_t)k];
                     if (key < *sl) atomicMin(sl, key);
                 }
             }
@@ -545,7 +548,7 @@ __device__ __forceinline__ void segment_body(
         // assignment back to the image
         const int o = pos[i];
         int yy = (int)((float)o * inv_bw);
-        int xx = o - yy * bw;
+        int xx = o - __mul24(yy, bw);
         if (xx < 0) {
             --yy;
             xx += bw;
@@ -553,7 +556,7 @@ __device__ __forceinline__ void segment_body(
             ++yy;
             xx -= bw;
         }
-        assign[img + (size_t)(ymin + yy) * W + xmin + xx] = (uint8_t)bi;
+        assign[img + (size_t)(uint32_t)(__mul24(ymin + yy, W) + xmin + xx)] = (uint8_t)bi;
     }
     __syncthreads();
     SEG_MARK(5)
@@ -607,9 +610,9 @@ __device__ __forceinline__ void segment_body(
             const uint32_t cell = keep[t] & 0xffffu;
             const uint8_t c = (uint8_t)(keep[t] >> 16);
             int yy = (int)((float)cell * inv_bw);
-            int xx = (int)cell - yy * bw;
+            int xx = (int)cell - __mul24(yy, bw);
             yy += (xx >= bw) - (xx < 0);
-            xx = (int)cell - yy * bw;
+            xx = (int)cell - __mul24(yy, bw);
             const bool up = yy > 0, lf = xx > 0, rt = xx < bw - 1;
             const bool n_ = up && cls[cell - bw] == c, w_ = lf && cls[cell - 1] == c;
             const bool nw = up && lf && cls[cell - bw - 1] == c;
@@ -751,7 +754,8 @@ extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int
     IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535 && H <= 65535,
                   "imgan_dcd_segments: bad shape");
     IMGAN_REQUIRE(k >= 1 && k <= KMAX, "imgan_dcd_segments: 1 <= k <= 16 dominant colours");
-    IMGAN_REQUIRE((long long)H * W < 0x7fffffffLL, "imgan_dcd_segments: image too large");
+    IMGAN_REQUIRE((long long)H * W < 0x7fffffffLL && W < (1 << 23),
+                  "imgan_dcd_segments: image too large");
     IMGAN_REQUIRE((long long)B * H * W >= 2, "imgan_dcd_segments: needs at least two pixels");
     IMGAN_REQUIRE(max_rounds >= 1, "imgan_dcd_segments: max_rounds must be positive");
     hipStream_t st = (hipStream_t)stream;
