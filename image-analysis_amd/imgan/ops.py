@@ -182,14 +182,27 @@ def rag_accumulate(img, labels, K, want_edges=True, edge_cap=None):
         if int(overflow.max().item()) == 0:
             break
         cap *= 4                                     # pathological adjacency: retry larger
+    # one sort and one transfer for the whole batch: keys are positive, so the empty slots (0)
+    # sort to the front of every row; (u+1)<<32 | (v+1) orders lexicographically by (u, v)
+    ordered, _ = torch.sort(table, dim=1)
+    counts = (table != 0).sum(dim=1).cpu().numpy()
+    width = int(counts.max()) if B else 0
+    host = ordered[:, cap - width:].cpu().numpy() if width else np.zeros((B, 0), dtype=np.int64)
     edges = []
     for b in range(B):
-        keys = table[b][table[b] != 0]
-        keys, _ = torch.sort(keys)                   # (u+1)<<32 | (v+1): lexicographic (u, v)
-        u = (keys >> 32) - 1
-        v = (keys & 0xffffffff) - 1
-        edges.append(torch.stack([u, v], dim=1).to(torch.int32).cpu().numpy())
+        keys = host[b, width - int(counts[b]):]
+        uv = np.stack([(keys >> 32) - 1, (keys & 0xffffffff) - 1], axis=1).astype(np.int32)
+        edges.append(uv.reshape(-1, 2))
     return sums, edges
+
+
+def rag_merge_batch(K, edges, sums, c_factor):
+    """The merge of rag_segmentation.py:77-184 for every image of a batch (means mode; host C++,
+    one image after the other: a merge takes a fraction of a millisecond, less than handing it
+    to a thread would cost).  sums: the [B,K,4] tensor of rag_accumulate.  Returns int32 [B,K]."""
+    s = sums.cpu().numpy()
+    means = np.where(s[:, :, 3:4] > 0, s[:, :, :3] // np.maximum(s[:, :, 3:4], 1), 0).astype(np.int32)
+    return np.stack([rag_merge_lut(K, edges[b], c_factor, means[b]) for b in range(len(edges))])
 
 
 def rag_merge_host(K, edges_uv, c_factor, means=None, weights=None):
@@ -224,6 +237,21 @@ def rag_merge_host(K, edges_uv, c_factor, means=None, weights=None):
     sets = [members[offsets[i]:offsets[i + 1]].tolist() for i in range(ns)]
     return {"lut": lut, "mst": mst[:n_mst.value].copy(), "mst_w": w[:n_mst.value].copy(),
             "sets": sets}
+
+
+def rag_merge_lut(K, edges_uv, c_factor, means):
+    """The relabel table only (int32 [K]) of rag_merge_host in means mode: the batch path needs
+    nothing else, and skipping the optional outputs keeps the per-image host cost small."""
+    edges_uv = np.ascontiguousarray(edges_uv, dtype=np.int32).reshape(-1, 2)
+    means = np.ascontiguousarray(means, dtype=np.int32)
+    E = edges_uv.shape[0]
+    lut = np.zeros(K, dtype=np.int32)
+    n_mst, n_sets = ctypes.c_int32(), ctypes.c_int32()
+    check(lib.imgan_rag_merge_host(means.ctypes.data, None, int(K),
+                                   edges_uv.ctypes.data if E else None, E, float(c_factor),
+                                   lut.ctypes.data, None, None, ctypes.byref(n_mst), None, None,
+                                   ctypes.byref(n_sets)))
+    return lut
 
 
 def relabel(labels, lut):

@@ -93,3 +93,49 @@ class FullPipeline(object):
         tot = float(npx.sum().item())
         r = float((rounds.to(torch.float64) * npx).sum().item()) / max(tot, 1.0)
         return max(r, float(self.dcd_rounds_run))
+
+
+class RagPipeline(object):
+    """Batch form of RAGSegmentation's sequence (rag_segmentation.py:10-25, 38-184) for
+    device-resident batches (BASELINE.json configs[2]): median 7x7 -> Lab -> SLIC -> per-label
+    means + adjacency -> MST merge with the leave-one-out cut (host C++, a few threads) ->
+    relabel.  Returns the merged label maps (int32, 0 = the unlabelled border)."""
+
+    def __init__(self, B, H, W, num_clusters, colour_weight=15, num_iter=10, c_factor=0.65):
+        self.B, self.H, self.W, self.K = int(B), int(H), int(W), int(num_clusters)
+        self.cw, self.num_iter, self.c_factor = colour_weight, int(num_iter), float(c_factor)
+        self.slic = ops.SlicPlan(B, H, W, num_clusters)
+        dev = self.slic.device
+        self.blur = torch.empty((self.B, self.H, self.W, 3), dtype=torch.uint8, device=dev)
+        self.lab = torch.empty_like(self.blur)
+        self.stage_events = {}
+        self.host_ms = {}
+
+    _timed = FullPipeline._timed
+
+    def step(self, bgr, timed=False):
+        import time
+        self._timed("median7", timed, lambda: ops.median7(bgr, out=self.blur))
+        self._timed("bgr2lab", timed, lambda: ops.bgr2lab(self.blur, out=self.lab))
+        self.slic.init(self.lab)
+        for _ in range(1, self.num_iter):
+            if timed:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                self.slic.round(self.lab, self.cw, events=ev)
+                self.stage_events.setdefault("slic_assign", []).append(ev)
+            else:
+                self.slic.round(self.lab, self.cw)
+        labels = self.slic.labels
+        t0 = time.perf_counter()
+        sums, edges = ops.rag_accumulate(self.lab, labels, self.K)      # synchronises (edge lists)
+        t1 = time.perf_counter()
+        luts = ops.rag_merge_batch(self.K, edges, sums, self.c_factor)
+        t2 = time.perf_counter()
+        merged = self._timed("relabel", timed,
+                             lambda: ops.relabel(labels, torch.from_numpy(luts).to(labels.device)))
+        if timed:
+            self.host_ms.setdefault("rag_accumulate+edge lists", []).append((t1 - t0) * 1e3)
+            self.host_ms.setdefault("host merge", []).append((t2 - t1) * 1e3)
+        return merged, luts
+
+    stage_times_ms = FullPipeline.stage_times_ms
