@@ -120,3 +120,23 @@ def test_adjacency_checkerboard_kat():
     img = torch.zeros((1, 3, 3, 3), dtype=torch.uint8, device="cuda")
     _, edges = ops.rag_accumulate(img, torch.from_numpy(lab).cuda().unsqueeze(0), 4)
     assert [tuple(e) for e in edges[0].tolist()] == [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+
+
+def test_rag_pipeline_batch_class_matches_oracle():
+    """imgan.pipeline.RagPipeline (median -> Lab -> SLIC -> sums/adjacency -> merge -> relabel on
+    a resident batch) against the oracle's per-image sequence."""
+    torch = _torch()
+    from imgan.pipeline import RagPipeline
+    from oracle.rag_ref import RAGOracle
+    K, H, W = 60, 120, 160
+    imgs = [voronoi_image(H, W, 8, seed=s) for s in (31, 32, 33)]
+    pipe = RagPipeline(len(imgs), H, W, K, colour_weight=15, num_iter=10, c_factor=0.65)
+    merged, luts = pipe.step(torch.from_numpy(np.stack(imgs)).cuda(), timed=True)
+    merged = merged.cpu().numpy()
+    for b, im in enumerate(imgs):
+        o = RAGOracle(im.copy(), slic_clust_num=K, slic_cw=15)
+        cl = o.run_slic()
+        want = o.concat_similar_regs(o.find_edges(o.neighbours_regions(cl), o.slic_mean_lab(cl)),
+                                     cl, 0.65)[0]
+        assert np.array_equal(merged[b].astype(np.float64), want), b
+    assert set(pipe.stage_times_ms()) >= {"median7", "bgr2lab", "slic_assign", "relabel"}
