@@ -554,14 +554,26 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
                     slot[j] = lt ? s : slot[j];
                 }
             };
+            // Two passes over the record, one per form of the body, so that each loop has a
+            // single body that updates best / slot in place (one loop with both forms merges
+            // their results through register copies on every iteration).  The order in which
+            // candidates are met does not matter: equal keys are always flagged and replayed.
+            unsigned long long partial = 0ull;           // candidates that hold some rows only
+            const unsigned all_lim = (unsigned)max(twoS - (R - 1), 0);
             for (int s = 0; s < m; ++s) {
                 const int8v c = rec[1 + s];
                 const int t0 = wy0 - c[1] + S;           // row j is inside iff 0 <= t0 + j < 2S
-                if (t0 + (R - 1) < 0 || t0 >= twoS) continue;  // no row of this wave inside
-                if (t0 >= 0 && t0 + (R - 1) < twoS)
-                    eval(s, c, t0, true);
-                else
-                    eval(s, c, t0, false);
+                if ((unsigned)t0 < all_lim) {
+                    eval(s, c, t0, true);                // every row of this wave inside
+                } else if ((unsigned)(t0 + (R - 1)) < (unsigned)(twoS + (R - 1))) {
+                    partial |= 1ull << s;
+                }
+            }
+            while (partial != 0ull) {
+                const int s = __builtin_ctzll(partial);
+                partial &= partial - 1ull;
+                const int8v c = rec[1 + s];
+                eval(s, c, wy0 - c[1] + S, false);
             }
             unsigned long long any_tie = 0ull;
 #pragma unroll
