@@ -349,6 +349,17 @@ __device__ __forceinline__ void flush_pixel_global(unsigned long long* sums, int
 // T is the same for every candidate of a pixel, so it cannot change which one wins: REL drops
 // it and compares the signed remainder (needs |key| < 2^31, checked on the host); otherwise
 // T is added and the comparison is unsigned below 2^32.  p . c is one v_dot4_u32_u8.
+__device__ __forceinline__ int smed3(int a, int b, int c) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int MODE, bool ALIGNED, bool REL, int R>
 __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restrict__ lab,
                                                           int32_t* __restrict__ labels, Ws w,
@@ -514,50 +525,43 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
         for (int j = 0; j < R; ++j) slot[j] = -1;
         unsigned tied = 0;                  // bit j: the best key of pixel j may have been met again
         if (MODE == 0) {
-            int best[R];
+            int best[R], best2[R];          // lowest and second lowest key met so far
             uint32_t T[R];
-            unsigned long long tie[R];      // lane masks (wave uniform values: scalar registers)
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                best[j] = REL ? 0x7fffffff : -1;
-                tie[j] = 0ull;
+                best[j] = best2[j] = REL ? 0x7fffffff : -1;
                 T[j] = 0;
                 if (!REL) {
                     const uint32_t pp = __builtin_amdgcn_udot4(px[j], px[j], 0u, false);
                     T[j] = pp * P.S2 + P.cw2 * (uint32_t)(xr * xr + (wy0 + j) * (wy0 + j));
                 }
             }
-            // No divergent branches in the loop: the column test (per lane) and the row tests
-            // (wave uniform) are lane masks in scalar registers that are and-ed into the
-            // compare results.  ALL: every row of the wave is inside the candidate's window
-            // (the common case), so only the column mask is left.
+            // The column test is the only per-lane condition: the lanes outside the candidate's
+            // columns sit out its whole body (one exec mask per candidate), the row tests are
+            // wave uniform.  ALL: every row of the wave is inside the candidate's window (the
+            // common case).  Equal keys: best2 follows the second lowest key with one median
+            // per evaluation (best <= best2 always holds, so median(key, best, best2) is the new
+            // second lowest); a pixel whose two lowest keys are equal is replayed exactly below.
             auto eval = [&](int s, const int8v& c, int t0, bool all_rows) {
-                const unsigned long long inxm =
-                    __builtin_amdgcn_ballot_w64((unsigned)(xr - c[0] + S) < (unsigned)twoS);
-                const int X = __mul24(-c[5], xr);
-                const int q0 = c[4] - c[6] * wy0;
-                const uint32_t cl = (uint32_t)c[2];
+                if ((unsigned)(xr - c[0] + S) < (unsigned)twoS) {
+                    const int X = __mul24(-c[5], xr) + (c[4] - c[6] * wy0);
+                    const uint32_t cl = (uint32_t)c[2];
 #pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const unsigned long long inm =
-                        (all_rows || (unsigned)(t0 + j) < (unsigned)twoS) ? inxm : 0ull;
-                    const int pc = (int)__builtin_amdgcn_udot4(px[j], cl, 0u, false);
-                    int key = __mul24(nS2x2, pc) + (X + (q0 - j * c[6]));
-                    if (!REL) key = (int)((uint32_t)key + T[j]);
-                    const unsigned long long ltm = __builtin_amdgcn_ballot_w64(
-                        REL ? key < best[j] : (uint32_t)key < (uint32_t)best[j]);
-                    // a key equal to the running best: flagged even when the candidate's window
-                    // does not hold the pixel (harmless, the replay below is exact)
-                    tie[j] |= __builtin_amdgcn_ballot_w64(key == best[j]);
-                    const bool lt = __builtin_amdgcn_inverse_ballot_w64(ltm & inm);
-                    best[j] = lt ? key : best[j];
-                    slot[j] = lt ? s : slot[j];
+                    for (int j = 0; j < R; ++j) {
+                        if (all_rows || (unsigned)(t0 + j) < (unsigned)twoS) {
+                            const int pc = (int)__builtin_amdgcn_udot4(px[j], cl, 0u, false);
+                            int key = __mul24(nS2x2, pc) + (X - j * c[6]);
+                            if (!REL) key = (int)((uint32_t)key + T[j]);
+                            best2[j] = REL ? smed3(key, best[j], best2[j])
+                                           : (int)umed3((uint32_t)key, (uint32_t)best[j],
+                                                        (uint32_t)best2[j]);
+                            const bool lt = REL ? key < best[j] : (uint32_t)key < (uint32_t)best[j];
+                            best[j] = lt ? key : best[j];
+                            slot[j] = lt ? s : slot[j];
+                        }
+                    }
                 }
             };
-            // Two passes over the record, one per form of the body, so that each loop has a
-            // single body that updates best / slot in place (one loop with both forms merges
-            // their results through register copies on every iteration).  The order in which
-            // candidates are met does not matter: equal keys are always flagged and replayed.
             unsigned long long partial = 0ull;           // candidates that hold some rows only
             const unsigned all_lim = (unsigned)max(twoS - (R - 1), 0);
             for (int s = 0; s < m; ++s) {
@@ -577,11 +581,11 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
             }
             unsigned long long any_tie = 0ull;
 #pragma unroll
-            for (int j = 0; j < R; ++j) any_tie |= tie[j];
+            for (int j = 0; j < R; ++j) any_tie |= __builtin_amdgcn_ballot_w64(best2[j] == best[j]);
             if (any_tie != 0ull) {                       // wave uniform, rarely taken
 #pragma unroll
                 for (int j = 0; j < R; ++j)
-                    tied |= (((tie[j] >> lane) & 1ull) != 0ull && slot[j] >= 0) ? (1u << j) : 0u;
+                    tied |= (best2[j] == best[j] && slot[j] >= 0) ? (1u << j) : 0u;
             }
         } else {
             typename KeyT<MODE>::type best[R];
@@ -631,24 +635,48 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
             }
         }
 
-        // ---- labels out + accumulate (a row of 64 labels per store instruction).  The 64-bit
-        // address is formed once per band and stepped by a row; LDS offsets use 24-bit
+        // ---- labels out + accumulate (a row of 64 labels per store instruction).  Row
+        // addresses are wave uniform (scalar base + lane offset); LDS offsets use 24-bit
         // multiplies (the 32-bit multiply-add of this chip is a quarter-rate 64-bit one).
-        int32_t* lrow = labels + ((size_t)b * H + (y0 + wy0)) * W + x;
+        int32_t* rowp = labels + ((size_t)b * H + (y0 + wy0)) * W + x0;
+        int lowest = slot[0];
 #pragma unroll
-        for (int j = 0; j < R; ++j, lrow += W) {
-            const int yr = wy0 + j, y = y0 + yr;
-            if (!(y < H - 1 && colok)) continue;
-            if (slot[j] >= 0) {
-                *lrow = s_c[slot[j]].w;
-                const uint32_t p = px[j];
-                uint32_t* a = acc + (__mul24(slot[j], 192) + lane);
-                atomicAdd(a, (p & 0xffu) | ((p & 0xff00u) << 8));
-                atomicAdd(a + 64, ((p >> 16) & 0xffu) | 0x10000u);
-                atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)yr << 16));
-            } else {
-                const int old = *lrow;                // not covered this round: keeps its label
-                if (old >= 0) flush_pixel_global(sums, old, px[j], x, y);
+        for (int j = 1; j < R; ++j) lowest = min(lowest, slot[j]);
+        const bool rows_full = y0 + wy0 + R <= H - 1;
+        if (rows_full && __builtin_amdgcn_ballot_w64(colok && lowest < 0) == 0ull) {
+            // the common case, free of per-row branches: every pixel of the wave has a centre
+            if (colok) {
+                int lbl[R];
+#pragma unroll
+                for (int j = 0; j < R; ++j) lbl[j] = s_c[slot[j]].w;
+#pragma unroll
+                for (int j = 0; j < R; ++j) (rowp + (size_t)j * W)[lane] = lbl[j];
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const uint32_t p = px[j];
+                    uint32_t* a = acc + (__mul24(slot[j], 192) + lane);
+                    atomicAdd(a, __builtin_amdgcn_perm(0u, p, 0x0c010c00u));          // L | a << 16
+                    atomicAdd(a + 64, __builtin_amdgcn_perm(0x01u, p, 0x0c040c02u));  // b | 1 << 16
+                    atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)(wy0 + j) << 16));
+                }
+            }
+        } else {
+            int32_t* lrow = rowp + lane;
+#pragma unroll
+            for (int j = 0; j < R; ++j, lrow += W) {
+                const int yr = wy0 + j, y = y0 + yr;
+                if (!(y < H - 1 && colok)) continue;
+                if (slot[j] >= 0) {
+                    *lrow = s_c[slot[j]].w;
+                    const uint32_t p = px[j];
+                    uint32_t* a = acc + (__mul24(slot[j], 192) + lane);
+                    atomicAdd(a, (p & 0xffu) | ((p & 0xff00u) << 8));
+                    atomicAdd(a + 64, ((p >> 16) & 0xffu) | 0x10000u);
+                    atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)yr << 16));
+                } else {
+                    const int old = *lrow;            // not covered this round: keeps its label
+                    if (old >= 0) flush_pixel_global(sums, old, px[j], x, y);
+                }
             }
         }
     }
