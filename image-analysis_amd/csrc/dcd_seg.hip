@@ -366,9 +366,11 @@ __device__ __forceinline__ void segment_body(
     if (tid == 0) s_done = 0;
     double old_sum = 0.0;              // only lane 0 of wave 0 uses its copy
     int rounds = 0;
-    // a q within 2^-17 of the smallest one replays the literal rule: 2^-20 for the sqrt rounding
-    // the fast loop skips, up to 2^-19 for the mantissa bits that carry the cluster index
-    const float NEAR = 1.0f - 7.62939453125e-06f;          // 1 - 2^-17
+    // a q within 2^-15 of the smallest one replays the literal rule.  What the fast loop leaves
+    // out, relative to q, for each of the two values compared: up to 2^-19 for the mantissa bits
+    // that carry the cluster index (twice: they are not masked off for the comparison either),
+    // 2^-22 for the fused multiply-adds, 2^-23 for the sqrt rounding -- under 2^-17 together.
+    const float NEAR = 1.0f - 3.0517578125e-05f;           // 1 - 2^-15
     constexpr uint32_t IDXM = KM - 1;
 
     // ---- Lloyd rounds (:85-107).  Two barriers per round: all waves assign, then the first
@@ -400,8 +402,11 @@ __device__ __forceinline__ void segment_body(
             uint32_t best = 0xffffffffu, second = 0xffffffffu;
 #pragma unroll
             for (int jj = 0; jj < KM / 2; ++jj) {
+                // fused multiply-adds: q differs from the literal (d0^2 + d1^2) + d2^2 by a few
+                // 2^-24 relative roundings, far inside the margin that NEAR leaves
                 const f32x2 d0 = F0 - c0[jj], d1 = F1 - c1[jj], d2 = F2 - c2[jj];
-                const f32x2 q = (d0 * d0 + d1 * d1) + d2 * d2;
+                const f32x2 q = __builtin_elementwise_fma(
+                    d2, d2, __builtin_elementwise_fma(d1, d1, d0 * d0));
                 const uint32_t kx = (__float_as_uint(q.x) & ~IDXM) | (uint32_t)(2 * jj);
                 const uint32_t ky = (__float_as_uint(q.y) & ~IDXM) | (uint32_t)(2 * jj + 1);
                 second = umed3(kx, best, second);
@@ -410,8 +415,7 @@ __device__ __forceinline__ void segment_body(
                 best = min(best, ky);
             }
             int bi = (int)(best & IDXM);
-            if (__builtin_expect(__fmul_rn(__uint_as_float(second & ~IDXM), NEAR) <
-                                 __uint_as_float(best & ~IDXM), 0)) {
+            if (__builtin_expect(__fmul_rn(__uint_as_float(second), NEAR) < __uint_as_float(best), 0)) {
                 float bs = __builtin_inff();
                 bi = 0;
                 for (int j = 0; j < k; ++j) {
@@ -427,8 +431,9 @@ __device__ __forceinline__ void segment_body(
             }
             pix[i] = (v & 0xffffffu) | ((uint32_t)bi << 24);
             if (PACKED) {
-                atomicAdd(&acc[(bi * 2) * 64 + lane], 1u | (u0 << 16));
-                atomicAdd(&acc[(bi * 2 + 1) * 64 + lane], u1 | (u2 << 16));
+                // byte shuffles: 1 | L << 16 and a | b << 16
+                atomicAdd(&acc[(bi * 2) * 64 + lane], __builtin_amdgcn_perm(1u, v, 0x0c000c04u));
+                atomicAdd(&acc[(bi * 2 + 1) * 64 + lane], __builtin_amdgcn_perm(0u, v, 0x0c020c01u));
             } else {
                 atomicAdd(&acc[(bi * 4) * 64 + lane], 1u);
                 atomicAdd(&acc[(bi * 4 + 1) * 64 + lane], u0);
