@@ -2,7 +2,7 @@
 # Builds libimgan_hip.so for gfx950 (cross-compiles without a GPU).
 set -e
 cd "$(dirname "$0")"
-OUT=../imgan/libimgan_hip.so
+OUT=${IMGAN_OUT:-../imgan/libimgan_hip.so}   # IMGAN_OUT: experiment builds (tools/)
 SRCS=$(ls *.hip)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
       -Wall -Wno-unused-function -Wno-unused-result \

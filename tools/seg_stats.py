@@ -17,6 +17,6 @@ print("area/count mean %.2f" % (area.sum() / cnt.sum()))
 r, d = pipe.dcd.rounds()
 r = r.cpu().numpy()
 print("rounds: mean %.2f max %d ; hist" % (r.mean(), r.max()), np.bincount(r.ravel())[:40])
-for cap in (6144, 7168, 7680, 8192, 11776):
+for cap in (8192, 9216, 10240, 10752, 11264, 11776):
     fit = (cnt <= cap) & (area * 3 + 8 <= cap * 6)
     print("cap %5d: %.1f %% of segments, %.1f %% of pixels fit" % (cap, 100.0 * fit.mean(), 100.0 * cnt[fit].sum() / cnt.sum()))
