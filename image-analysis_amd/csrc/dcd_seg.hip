@@ -262,11 +262,12 @@ __device__ __forceinline__ void segment_body(
         const float inv_bw = 1.0f / (float)bw;
         const size_t last_px = (size_t)B * H * W - 1;
         const bool kpow2 = (k & (k - 1)) == 0;
-        for (int i0 = 0; i0 < area; i0 += THREADS * 4) {
-            int lbl[4], off[4];
-            uint32_t pp[4], raw[4], sh[4];
+        constexpr int GU = 8;                           // cells per thread and step
+        for (int i0 = 0; i0 < area; i0 += THREADS * GU) {
+            int lbl[GU], off[GU];
+            uint32_t pp[GU], raw[GU], sh[GU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < GU; ++u) {
                 const int i = i0 + u * THREADS + tid;
                 off[u] = i;
                 const int ic = i < area ? i : area - 1;
@@ -284,29 +285,30 @@ __device__ __forceinline__ void segment_body(
                 sh[u] = gp == last_px ? 1u : 0u;
                 raw[u] = *reinterpret_cast<const u32_unaligned*>(lab + ((gp << 1) + gp) - sh[u]);
             }
-            uint32_t v[4];
-            int slot[4];
+            // one LDS atomic per wave and step: lane 0 reserves the slots of all GU ballots
+            unsigned long long who[GU];
+            int total = 0;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < GU; ++u) {
                 if (off[u] >= area) lbl[u] = -2;
-                const bool m = lbl[u] == s;
-                // one LDS atomic per wave: the leader reserves a run of slots
-                const unsigned long long who = __ballot(m);
-                int base = 0;
-                if (who) {
-                    const int leader = __ffsll((long long)who) - 1;
-                    if (lane == leader) base = atomicAdd(&s_n, __popcll(who));
-                    base = __shfl(base, leader);
-                }
-                slot[u] = base + __popcll(who & ((1ull << lane) - 1ull));
-                v[u] = (raw[u] >> (8u * sh[u])) & 0xffffffu;
+                who[u] = __ballot(lbl[u] == s);
+                total += __popcll(who[u]);
             }
+            int base = 0;
+            if (total) {                                // wave uniform
+                if (lane == 0) base = atomicAdd(&s_n, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < GU; ++u) {
+                const int slot = base + __popcll(who[u] & below);
+                base += __popcll(who[u]);
                 if (lbl[u] != s) continue;
-                if (slot[u] < CAP) {
-                    pix[slot[u]] = v[u];
-                    pos[slot[u]] = (uint16_t)off[u];
+                const uint32_t v = (raw[u] >> (8u * sh[u])) & 0xffffffu;
+                if (slot < CAP) {
+                    pix[slot] = v;
+                    pos[slot] = (uint16_t)off[u];
                 }
                 if (use_hash) {
                     // stand-in for random.sample (:79): slot h % k goes to the smallest (h, p)
