@@ -137,17 +137,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the HIP path is the only path)")
+    # IMGAN_BENCH_REHEARSAL=1: every rank on device 0 over gloo, to walk the N > 1 control flow on
+    # a one-GPU box (RCCL refuses two ranks on one device); never set by the driver
+    rehearsal = os.environ.get("IMGAN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     B, H, W, K = args.batch, args.height, args.width, args.clusters
     cw, num_iter = 15, 10
     bgr = synth_batch(B, H, W, K, 1234 + rank * B, "cuda")
     from imgan.pipeline import FullPipeline
-    from imgan.shard import gather_descriptors
+    from imgan.shard import gather_descriptors_async
     pipe = FullPipeline(B, H, W, K, colour_weight=cw, num_iter=num_iter, dominant=8)
 
     def barrier():
@@ -155,16 +163,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    index = None
+    index, pending = None, None
     for _ in range(args.warmup):
         pipe.step(bgr)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         image_rows, region_rows = pipe.step(bgr, timed=True)
-        # one collective per step: the descriptor rows of every rank -> replicated index
-        index = (gather_descriptors(image_rows, n_total=B * world),
-                 gather_descriptors(region_rows, n_total=B * world))
+        # one collective per step: the descriptor rows of every rank -> replicated index.  It is
+        # left in flight (RCCL's own stream) while the next step is enqueued, and joined after.
+        if pending is not None:
+            index = (pending[0].result(), pending[1].result())
+        pending = (gather_descriptors_async(image_rows, n_total=B * world),
+                   gather_descriptors_async(region_rows, n_total=B * world))
+    index = (pending[0].result(), pending[1].result()) if pending is not None else None
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")

@@ -15,14 +15,38 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_descriptors(local, n_total=None, group=None):
+class PendingGather:
+    """An all-gather in flight (gather_descriptors_async).  result() makes the current stream
+    wait for it and returns the [n_total, D] matrix."""
+
+    def __init__(self, out, work=None, sizes=None, width=0):
+        self._out, self._work, self._sizes, self._width = out, work, sizes, width
+
+    def result(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        out, sizes, width = self._out, self._sizes, self._width
+        if sizes is None or all(s == width for s in sizes):
+            return out
+        parts = [out[r * width:r * width + sizes[r]] for r in range(len(sizes))]
+        return torch.cat(parts, dim=0)
+
+
+def gather_descriptors_async(local, n_total=None, group=None):
     """All-gather [n_local, D] descriptor rows of every rank into [n_total, D] (rank order =
-    image order, because shards are contiguous).  Ragged shards are padded to the largest
-    shard for the collective and trimmed afterwards."""
+    image order, because shards are contiguous) without waiting for it: the collective runs on
+    the backend's own stream while the caller enqueues the next batch.  The rows are copied
+    first, so the caller may overwrite `local` at once.  Ragged shards are padded to the
+    largest shard for the collective and trimmed in result()."""
     if not dist.is_available() or not dist.is_initialized():
-        return local
+        return PendingGather(local)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no all-gather for device tensors (rehearsals of the N > 1 flow on one GPU)
+        return PendingGather(gather_descriptors_async(local.cpu(), n_total, group).result()
+                             .to(local.device))
     if n_total is None:
         counts = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
         all_counts = [torch.zeros_like(counts) for _ in range(world)]
@@ -34,15 +58,14 @@ def gather_descriptors(local, n_total=None, group=None):
     if sizes[rank] != local.shape[0]:
         raise ValueError("rank %d holds %d rows, expected %d" % (rank, local.shape[0], sizes[rank]))
     width = max(sizes)
-    padded = local
-    if local.shape[0] < width:
-        pad = torch.zeros((width - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
-                          device=local.device)
-        padded = torch.cat([local, pad], dim=0)
+    padded = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
     out = torch.empty((world * width,) + tuple(local.shape[1:]), dtype=local.dtype,
                       device=local.device)
-    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
-    if all(s == width for s in sizes):
-        return out
-    parts = [out[r * width:r * width + sizes[r]] for r in range(world)]
-    return torch.cat(parts, dim=0)
+    work = dist.all_gather_into_tensor(out, padded, group=group, async_op=True)
+    return PendingGather(out, work, sizes, width)
+
+
+def gather_descriptors(local, n_total=None, group=None):
+    """Blocking form of gather_descriptors_async."""
+    return gather_descriptors_async(local, n_total, group).result()

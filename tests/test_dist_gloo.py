@@ -33,6 +33,10 @@ def _worker(rank, world, port, n_total, width, out_dir):
         torch.arange(width, dtype=torch.float32).view(1, -1)
     full = gather_descriptors(rows, n_total=n_total)
     full2 = gather_descriptors(rows)                      # sizes discovered by a collective
+    from imgan.shard import gather_descriptors_async
+    pending = gather_descriptors_async(rows, n_total=n_total)
+    rows.fill_(-1.0)                                      # the caller may reuse its buffer at once
+    assert torch.equal(pending.result(), full)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), full.numpy())
     assert torch.equal(full, full2)
     dist.barrier()
