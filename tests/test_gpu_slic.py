@@ -48,6 +48,9 @@ CASES = [
     (101, 157, 60, 15, 6),         # unaligned rows
     (270, 480, 100, 10, 10),
     (96, 128, 12, 40, 4),          # large step -> u64 key path check via cw
+    (200, 260, 16, 15, 10),        # S = 57: two bands per tile, 8 rows per lane, 32 x 16 wave patches
+    (203, 259, 16, 15, 5),         # the same with unaligned rows
+    (300, 420, 12, 15, 4),         # S = 102
 ]
 
 
