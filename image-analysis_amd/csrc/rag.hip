@@ -13,7 +13,10 @@
 #include "../../include/imgan.h"
 #include <algorithm>
 #include <math.h>
+#include <atomic>
 #include <numeric>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -337,5 +340,46 @@ extern "C" int imgan_rag_merge_host(const int32_t* means, const double* weights,
     }
     if (set_offsets_out) set_offsets_out[id] = pos;
     *n_sets_out = id;
+    return 0;
+}
+
+// The merge of every image of a batch (means mode, relabel table only), on `threads` host
+// threads that take images from a shared counter: a merge is a few hundred microseconds of
+// sorting and union-find, so a batch of 4K frames is bound by this loop when it runs serially.
+extern "C" int imgan_rag_merge_host_batch(const int32_t* means, int B, int K,
+                                          const int32_t* edges_uv, const int64_t* edge_offsets,
+                                          double c_factor, int32_t* lut_out, int threads) {
+    IMGAN_REQUIRE(means && edge_offsets && lut_out, "imgan_rag_merge_host_batch: null pointer");
+    IMGAN_REQUIRE(B >= 1 && K >= 1, "imgan_rag_merge_host_batch: bad sizes");
+    for (int b = 0; b < B; ++b)
+        IMGAN_REQUIRE(edge_offsets[b] >= 0 && edge_offsets[b] <= edge_offsets[b + 1],
+                      "imgan_rag_merge_host_batch: edge offsets must ascend");
+    IMGAN_REQUIRE(edge_offsets[B] == 0 || edges_uv, "imgan_rag_merge_host_batch: null edge list");
+    const int nt = std::max(1, std::min(std::min(threads, B), 64));
+    std::atomic<int> next(0), rc_all(0);
+    std::string first_error;
+    std::atomic<bool> have_error(false);
+    auto work = [&]() {
+        for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) {
+            int32_t n_mst = 0, n_sets = 0;
+            const int64_t lo = edge_offsets[b], E = edge_offsets[b + 1] - lo;
+            const int rc = imgan_rag_merge_host(means + (size_t)b * K * 3, nullptr, K,
+                                                E ? edges_uv + 2 * lo : nullptr, E, c_factor,
+                                                lut_out + (size_t)b * K, nullptr, nullptr, &n_mst,
+                                                nullptr, nullptr, &n_sets);
+            if (rc != 0 && !have_error.exchange(true)) {     // the message is per thread: keep one
+                rc_all = rc;
+                first_error = imgan_last_error();
+            }
+        }
+    };
+    if (nt == 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+        for (auto& th : pool) th.join();
+    }
+    if (have_error) return imgan::fail(rc_all, first_error);
     return 0;
 }

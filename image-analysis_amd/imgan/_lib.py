@@ -37,6 +37,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "imgan_rag_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p, c_i64, c_void_p, c_void_p]),
+    "imgan_rag_merge_host_batch": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_double,
+                                           c_void_p, c_int]),
     "imgan_rag_merge_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_i64, c_double,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),

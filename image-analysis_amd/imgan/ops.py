@@ -196,13 +196,24 @@ def rag_accumulate(img, labels, K, want_edges=True, edge_cap=None):
     return sums, edges
 
 
-def rag_merge_batch(K, edges, sums, c_factor):
-    """The merge of rag_segmentation.py:77-184 for every image of a batch (means mode; host C++,
-    one image after the other: a merge takes a fraction of a millisecond, less than handing it
-    to a thread would cost).  sums: the [B,K,4] tensor of rag_accumulate.  Returns int32 [B,K]."""
+def rag_merge_batch(K, edges, sums, c_factor, threads=16):
+    """The merge of rag_segmentation.py:77-184 for every image of a batch (means mode; host C++
+    in the library, the images spread over `threads` host threads).  sums: the [B,K,4] tensor of
+    rag_accumulate; edges: one int [E_b, 2] array per image.  Returns int32 [B,K]."""
     s = sums.cpu().numpy()
-    means = np.where(s[:, :, 3:4] > 0, s[:, :, :3] // np.maximum(s[:, :, 3:4], 1), 0).astype(np.int32)
-    return np.stack([rag_merge_lut(K, edges[b], c_factor, means[b]) for b in range(len(edges))])
+    means = np.ascontiguousarray(
+        np.where(s[:, :, 3:4] > 0, s[:, :, :3] // np.maximum(s[:, :, 3:4], 1), 0).astype(np.int32))
+    B = len(edges)
+    offsets = np.zeros(B + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(e) for e in edges])
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(e, dtype=np.int32).reshape(-1, 2)
+                                                for e in edges]) if offsets[B] else
+                                np.zeros((1, 2), np.int32))
+    luts = np.zeros((B, K), dtype=np.int32)
+    check(lib.imgan_rag_merge_host_batch(means.ctypes.data, B, int(K), flat.ctypes.data,
+                                         offsets.ctypes.data, float(c_factor), luts.ctypes.data,
+                                         int(threads)))
+    return luts
 
 
 def rag_merge_host(K, edges_uv, c_factor, means=None, weights=None):

@@ -115,6 +115,14 @@ int imgan_rag_merge_host(const int32_t* means, const double* weights, int K,
                          int32_t* mst_out, double* mst_w_out, int32_t* n_mst_out,
                          int32_t* members_out, int32_t* set_offsets_out, int32_t* n_sets_out);
 
+/* The same merge (means mode, relabel table only) for every image of a batch, on up to
+ * `threads` host threads (rag_segmentation.py:77-184 per image; the caller's loop over images,
+ * basegen.py:96-99).  HOST pointers: means int32 [B][K][3]; edges_uv int32 [edge_offsets[B]][2],
+ * image b owns edges edge_offsets[b] .. edge_offsets[b+1]-1; lut_out int32 [B][K]. */
+int imgan_rag_merge_host_batch(const int32_t* means, int B, int K, const int32_t* edges_uv,
+                               const int64_t* edge_offsets, double c_factor, int32_t* lut_out,
+                               int threads);
+
 /* rag_segmentation.py:175-182: out[p] = lut[labels[p]] (labels[p] < 0 or >= K -> 0).
  * lut: int32 [B][K] device. */
 int imgan_relabel_lut(const int32_t* labels, const int32_t* lut, int32_t* out, int B,

@@ -122,6 +122,42 @@ def test_product_path_needs_the_gpu():
         SLICSuperPixel(None, 10)             # slic.py:10-11 check comes first
 
 
+def test_rag_merge_host_batch_equals_per_image_merges():
+    """imgan_rag_merge_host_batch (images spread over host threads) against one
+    imgan_rag_merge_host call per image, ragged edge lists, an image without edges, and the
+    error of a worker thread reaching the caller."""
+    import ctypes
+    from imgan import ops
+
+    class FakeSums(object):                       # rag_merge_batch only calls .cpu().numpy()
+        def __init__(self, a):
+            self.a = a
+
+        def cpu(self):
+            return self
+
+        def numpy(self):
+            return self.a
+
+    rng = np.random.RandomState(5)
+    B, K = 9, 40
+    sums = rng.randint(0, 4000, (B, K, 4)).astype(np.int64)
+    sums[:, :, 3] = rng.randint(0, 30, (B, K))     # some empty labels (count 0 -> mean 0)
+    edges = []
+    for b in range(B):
+        E = 0 if b == 3 else rng.randint(1, 120)
+        uv = rng.randint(0, K, (E, 2))
+        edges.append(uv[uv[:, 0] != uv[:, 1]].astype(np.int32))
+    for threads in (1, 4, 64):
+        luts = ops.rag_merge_batch(K, edges, FakeSums(sums), 0.65, threads=threads)
+        for b in range(B):
+            means = np.where(sums[b, :, 3:4] > 0, sums[b, :, :3] // np.maximum(sums[b, :, 3:4], 1), 0)
+            assert np.array_equal(luts[b], ops.rag_merge_lut(K, edges[b], 0.65, means)), (threads, b)
+    edges[5] = np.array([[0, K + 3]], np.int32)
+    with pytest.raises(ValueError):
+        ops.rag_merge_batch(K, edges, FakeSums(sums), 0.65, threads=4)
+
+
 def test_product_does_not_import_oracle():
     """The oracle is test infrastructure: nothing under image-analysis_amd/ may import,
     include, load or execute it."""
