@@ -751,11 +751,10 @@ extern "C" size_t imgan_dcd_bbox_bytes(int B, int nseg) {
                                          imgan::align_up(((size_t)B * nseg + 1) * 4, 256);
 }
 
-extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
-                                  int nseg, int k, int use_hash_init, uint32_t seed,
-                                  float* centres, uint8_t* assign, void* state, uint64_t* stats,
-                                  void* bbox_scratch, int32_t* n_big_out, int max_rounds,
-                                  imgan_stream_t stream) {
+static int dcd_segments(const uint8_t* lab, const int32_t* labels, int B, int H, int W, int nseg,
+                        int k, int use_hash_init, uint32_t seed, float* centres, uint8_t* assign,
+                        void* state, uint64_t* stats, void* bbox_scratch, bool have_bbox,
+                        int32_t* n_big_out, int max_rounds, imgan_stream_t stream) {
     IMGAN_REQUIRE(lab && labels && centres && assign && state && stats && bbox_scratch && n_big_out,
                   "imgan_dcd_segments: null pointer");
     IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535 && H <= 65535,
@@ -773,10 +772,12 @@ extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int
     IMGAN_HIP(hipMemsetAsync(state, 0, L.total, st));
     IMGAN_HIP(hipMemsetAsync(n_big_out, 0, 4, st));
     IMGAN_HIP(hipMemsetAsync(assign, 0xff, (size_t)B * H * W, st));
-    hipLaunchKernelGGL(seg_bbox_init_kernel, dim3((unsigned)imgan::cdiv((long long)nsegs, 256)),
-                       dim3(256), 0, st, bbox, (int)nsegs);
-    dim3 gb((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, BBOX_ROWS), (unsigned)B);
-    hipLaunchKernelGGL(seg_bbox_kernel, gb, dim3(256), 0, st, labels, H, W, nseg, bbox);
+    if (!have_bbox) {
+        hipLaunchKernelGGL(seg_bbox_init_kernel, dim3((unsigned)imgan::cdiv((long long)nsegs, 256)),
+                           dim3(256), 0, st, bbox, (int)nsegs);
+        dim3 gb((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, BBOX_ROWS), (unsigned)B);
+        hipLaunchKernelGGL(seg_bbox_kernel, gb, dim3(256), 0, st, labels, H, W, nseg, bbox);
+    }
     int* retry = (int*)((char*)bbox_scratch + imgan::align_up(nsegs * 4 * 4 + 16, 256));
     IMGAN_HIP(hipMemsetAsync(retry, 0, 4, st));
     dim3 gs((unsigned)nseg, (unsigned)B);
@@ -796,6 +797,24 @@ extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int
     }
 #undef TIER
     return imgan::check_launch("imgan_dcd_segments");
+}
+
+extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
+                                  int nseg, int k, int use_hash_init, uint32_t seed,
+                                  float* centres, uint8_t* assign, void* state, uint64_t* stats,
+                                  void* bbox_scratch, int32_t* n_big_out, int max_rounds,
+                                  imgan_stream_t stream) {
+    return dcd_segments(lab, labels, B, H, W, nseg, k, use_hash_init, seed, centres, assign, state,
+                        stats, bbox_scratch, false, n_big_out, max_rounds, stream);
+}
+
+extern "C" int imgan_dcd_segments_boxed(const uint8_t* lab, const int32_t* labels, int B, int H,
+                                        int W, int nseg, int k, int use_hash_init, uint32_t seed,
+                                        float* centres, uint8_t* assign, void* state,
+                                        uint64_t* stats, void* bbox_scratch, int32_t* n_big_out,
+                                        int max_rounds, imgan_stream_t stream) {
+    return dcd_segments(lab, labels, B, H, W, nseg, k, use_hash_init, seed, centres, assign, state,
+                        stats, bbox_scratch, true, n_big_out, max_rounds, stream);
 }
 
 extern "C" int imgan_label_bbox(const int32_t* labels, int B, int H, int W, int nseg,

@@ -208,6 +208,7 @@ struct AssignParams {
     long long ntiles;         // B * ntx * nty
     unsigned S2, cw2;         // integer key weights (modes 0, 1); cw2 = 0 in mode 2
     double Sd, cw;            // literal float64 evaluation (mode 2 and exact-key ties)
+    int* bbox;                // NULL, or [B][n][4] xmin, ymin, xmax, ymax of the new label map
 };
 
 // One wave per assignment tile: collects the centres whose window can reach the tile from the
@@ -333,6 +334,19 @@ __device__ __forceinline__ void flush_pixel_global(unsigned long long* sums, int
     atomicAdd(&s[5], 1ull);
 }
 
+__device__ __forceinline__ void bbox_point_global(int* bb, int xa, int ya, int xb, int yb) {
+    atomicMin(&bb[0], xa);
+    atomicMin(&bb[1], ya);
+    atomicMax(&bb[2], xb);
+    atomicMax(&bb[3], yb);
+}
+
+__global__ void slic_bbox_init_kernel(int* __restrict__ bbox, int total) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    reinterpret_cast<int4*>(bbox)[t] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
+}
+
 // MODE 0: 32-bit key with the dot4 expansion (fast path); 1: u64; 2: literal float64.
 // REL (mode 0 only): the key is kept relative to its per-pixel constant (see below).
 //
@@ -371,6 +385,10 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
     int4* s_c = reinterpret_cast<int4*>(smem);                  // by rank: {cx', cy', lab, idx}
     uint32_t* acc = reinterpret_cast<uint32_t*>(s_c + maxc);    // [slot][word][lane] partial sums
     uint32_t* tr = acc + maxc * 192;                            // [wave][row][column] transposition
+    // bounding boxes of the new labels (P.bbox, last round only): the columns of a slot are the
+    // lanes whose count is not zero; its rows come from a lane-private min / max pair
+    uint32_t* ybox = tr + 4 * R * 64;                           // [slot][min, max][lane]
+    int* const bbox = P.bbox;                                   // wave uniform
 
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2),
     // so XCD k takes the k-th contiguous eighth of the tile list.  Horizontally adjacent
@@ -428,6 +446,8 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
     }
     for (int i = tid; i < maxc * 3 * 16; i += 256)
         reinterpret_cast<uint4*>(acc)[i] = make_uint4(0, 0, 0, 0);
+    if (bbox)
+        for (int i = tid; i < maxc * 128; i += 256) ybox[i] = (i & 64) ? 0u : 0x7fffffffu;
 
     const int xr = lane;                                 // tile relative column of this lane
     const int x = x0 + xr;
@@ -477,7 +497,10 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
                 labels[li] = bi;
             else
                 lbl = labels[li];
-            if (lbl >= 0) flush_pixel_global(sums, lbl, px, x, y);
+            if (lbl >= 0) {
+                flush_pixel_global(sums, lbl, px, x, y);
+                if (bbox) bbox_point_global(bbox + ((size_t)b * n + lbl) * 4, x, y, x, y);
+            }
         }
         return;
     }
@@ -659,6 +682,14 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
                     atomicAdd(a + 64, __builtin_amdgcn_perm(0x01u, p, 0x0c040c02u));  // b | 1 << 16
                     atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)(wy0 + j) << 16));
                 }
+                if (bbox) {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        uint32_t* q = ybox + (__mul24(slot[j], 128) + lane);
+                        atomicMin(q, (uint32_t)(wy0 + j));
+                        atomicMax(q + 64, (uint32_t)(wy0 + j));
+                    }
+                }
             }
         } else {
             int32_t* lrow = rowp + lane;
@@ -673,9 +704,17 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
                     atomicAdd(a, (p & 0xffu) | ((p & 0xff00u) << 8));
                     atomicAdd(a + 64, ((p >> 16) & 0xffu) | 0x10000u);
                     atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)yr << 16));
+                    if (bbox) {
+                        uint32_t* q = ybox + (__mul24(slot[j], 128) + lane);
+                        atomicMin(q, (uint32_t)yr);
+                        atomicMax(q + 64, (uint32_t)yr);
+                    }
                 } else {
                     const int old = *lrow;            // not covered this round: keeps its label
-                    if (old >= 0) flush_pixel_global(sums, old, px[j], x, y);
+                    if (old >= 0) {
+                        flush_pixel_global(sums, old, px[j], x, y);
+                        if (bbox) bbox_point_global(bbox + ((size_t)b * n + old) * 4, x, y, x, y);
+                    }
                 }
             }
         }
@@ -716,6 +755,37 @@ __global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restr
                 atomicAdd(&dst[3], (unsigned long long)lo + (unsigned long long)cnt * x0);
                 atomicAdd(&dst[4], (unsigned long long)hi + (unsigned long long)cnt * y0);
             }
+        }
+    }
+    if (bbox) {
+        // 16 lanes per slot, 4 columns per lane: the columns that hold the slot (count != 0)
+        // give the x range directly, their row extremes the y range; one global update per
+        // (tile, slot) and bound
+        for (int s0 = 0; s0 < m; s0 += 16) {
+            const int s = s0 + (tid >> 4), t16 = tid & 15;
+            int xa = 0x7fffffff, ya = 0x7fffffff, xb = -1, yb = -1;
+            if (s < m) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int col = 4 * t16 + c;
+                    if ((acc[(s * 3 + 1) * 64 + col] >> 16) != 0u) {
+                        xa = min(xa, col);
+                        xb = max(xb, col);
+                        ya = min(ya, (int)ybox[s * 128 + col]);
+                        yb = max(yb, (int)ybox[s * 128 + 64 + col]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                xa = min(xa, __shfl_xor(xa, o));
+                ya = min(ya, __shfl_xor(ya, o));
+                xb = max(xb, __shfl_xor(xb, o));
+                yb = max(yb, __shfl_xor(yb, o));
+            }
+            if (s < m && t16 == 0 && xb >= 0)
+                bbox_point_global(bbox + ((size_t)b * n + s_c[s].w) * 4, x0 + xa, y0 + ya, x0 + xb,
+                                  y0 + yb);
         }
     }
 }
@@ -809,6 +879,7 @@ AssignParams make_params(int B, int H, int W, int S, int n, double colour_weight
     // LDS is sized for about twice the expected number of centres around a tile
     double m_est = (double)(TW + 2 * S) * (L.tile_h + 2 * S) / ((double)S * S);
     P.maxc = std::min(MAXC, std::max(16, ((int)(2.0 * m_est) + 4 + 7) / 8 * 8));
+    P.bbox = nullptr;
     return P;
 }
 
@@ -838,9 +909,9 @@ extern "C" int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres
     return imgan::check_launch("slic_bin_centres");
 }
 
-extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H,
-                                            int W, int S, int n, double colour_weight,
-                                            void* workspace, imgan_stream_t stream) {
+static int assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H, int W, int S, int n,
+                             double colour_weight, void* workspace, int32_t* bbox_out,
+                             imgan_stream_t stream) {
     IMGAN_REQUIRE(lab && labels && workspace, "imgan_slic_assign_accumulate: null pointer");
     if (int rc = validate("imgan_slic_assign_accumulate", B, H, W, S, n)) return rc;
     IMGAN_REQUIRE(colour_weight > 0.0 && isfinite(colour_weight),
@@ -857,6 +928,12 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
     IMGAN_REQUIRE((P.ntiles + 7) / 8 * 8 < 0x7fffffffLL, "imgan_slic_assign_accumulate: too many tiles");
     dim3 grid((unsigned)((P.ntiles + 7) / 8 * 8));
     hipStream_t st = (hipStream_t)stream;
+    if (bbox_out) {
+        P.bbox = bbox_out;
+        lds_bytes += (size_t)P.maxc * 2 * 64 * sizeof(uint32_t);
+        hipLaunchKernelGGL(slic_bbox_init_kernel, dim3((unsigned)imgan::cdiv(B * n, 256)), dim3(256),
+                           0, st, bbox_out, B * n);
+    }
 #define LAUNCH1(M, A, E, RR) hipLaunchKernelGGL((slic_assign_kernel<M, A, E, RR>), grid, dim3(256), lds_bytes, st, lab, labels, w, P)
 #define LAUNCH(M, A, E) do { if (rows == 8) LAUNCH1(M, A, E, 8); else LAUNCH1(M, A, E, 4); } while (0)
     if (mode == 0 && rel) { if (aligned) LAUNCH(0, true, true); else LAUNCH(0, false, true); }
@@ -866,6 +943,20 @@ extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels,
 #undef LAUNCH
 #undef LAUNCH1
     return imgan::check_launch("slic_assign_kernel");
+}
+
+extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H,
+                                            int W, int S, int n, double colour_weight,
+                                            void* workspace, imgan_stream_t stream) {
+    return assign_accumulate(lab, labels, B, H, W, S, n, colour_weight, workspace, nullptr, stream);
+}
+
+extern "C" int imgan_slic_assign_accumulate_bbox(const uint8_t* lab, int32_t* labels, int B, int H,
+                                                 int W, int S, int n, double colour_weight,
+                                                 void* workspace, int32_t* bbox_out,
+                                                 imgan_stream_t stream) {
+    IMGAN_REQUIRE(bbox_out, "imgan_slic_assign_accumulate_bbox: null pointer");
+    return assign_accumulate(lab, labels, B, H, W, S, n, colour_weight, workspace, bbox_out, stream);
 }
 
 extern "C" int imgan_slic_finalise_centres(int32_t* centres, int B, int H, int W, int S, int n,

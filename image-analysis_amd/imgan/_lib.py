@@ -31,6 +31,8 @@ SIGNATURES = {
                                        c_double, c_void_p, c_void_p]),
     "imgan_slic_assign_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                              c_double, c_void_p, c_void_p]),
+    "imgan_slic_assign_accumulate_bbox": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                  c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "imgan_slic_finalise_centres": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                             c_void_p]),
     "imgan_slic_run": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_int,
@@ -55,6 +57,9 @@ SIGNATURES = {
     "imgan_dcd_segments": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    ctypes.c_uint32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int, c_void_p]),
+    "imgan_dcd_segments_boxed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         ctypes.c_uint32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int, c_void_p]),
     "imgan_dcd_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "imgan_dcd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),

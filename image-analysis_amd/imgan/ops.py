@@ -118,18 +118,27 @@ class SlicPlan(object):
                                   _ptr(self.centres), _ptr(self.labels), _ptr(self.workspace),
                                   _stream()))
 
-    def round(self, lab, colour_weight, events=None):
+    def round(self, lab, colour_weight, events=None, bbox=None):
         """One iteration of slic.py:84-126.  `events`: optional (start, end) torch events
-        recorded around the assignment kernel on the current stream (bench.py roofline)."""
+        recorded around the assignment kernel on the current stream (bench.py roofline).
+        `bbox`: optional device buffer of at least B*n*16 bytes that receives the bounding box
+        int32 [B,n,4] of every label of the updated map (for DcdPlan.kmeans(boxed=True))."""
         lab = self._check(lab)
         a = (self.B, self.H, self.W, self.S, self.n)
         check(lib.imgan_slic_bin_centres(_ptr(lab), _ptr(self.centres), *a, float(colour_weight),
                                          _ptr(self.workspace), _stream()))
         if events:
             events[0].record()
-        check(lib.imgan_slic_assign_accumulate(_ptr(lab), _ptr(self.labels), *a,
-                                               float(colour_weight), _ptr(self.workspace),
-                                               _stream()))
+        if bbox is None:
+            check(lib.imgan_slic_assign_accumulate(_ptr(lab), _ptr(self.labels), *a,
+                                                   float(colour_weight), _ptr(self.workspace),
+                                                   _stream()))
+        else:
+            if bbox.numel() * bbox.element_size() < self.B * self.n * 16:
+                raise ValueError("bbox buffer too small")
+            check(lib.imgan_slic_assign_accumulate_bbox(_ptr(lab), _ptr(self.labels), *a,
+                                                        float(colour_weight), _ptr(self.workspace),
+                                                        _ptr(bbox), _stream()))
         if events:
             events[1].record()
         check(lib.imgan_slic_finalise_centres(_ptr(self.centres), *a, _ptr(self.workspace),
@@ -336,11 +345,12 @@ class DcdPlan(object):
         self.big_segments = 0
 
     def kmeans(self, lab, labels, centres, seed=None, max_rounds=1000, check_every=1,
-               streaming_only=False):
+               streaming_only=False, boxed=False):
         """Runs every segment's Lloyd loop to the reference's stop rule.
         centres: float32 [B,nseg,k,3], updated in place; with seed is not None they are
         sampled on the device (hash rule of imgan_dcd_init_hash), otherwise they must hold
-        the initial centres."""
+        the initial centres.  boxed: self.bbox already holds the bounding boxes of `labels`
+        (SlicPlan.round(..., bbox=self.bbox) on the round that made them)."""
         lab = as_batch(_dev(lab, torch.uint8, "lab"))
         if labels.dim() == 2:
             labels = labels.unsqueeze(0)
@@ -357,10 +367,10 @@ class DcdPlan(object):
             self.big_segments = self.B * self.nseg
             state_for_skip = None
         else:
-            check(lib.imgan_dcd_segments(_ptr(lab), _ptr(labels), *shape, 1 if use_hash else 0,
-                                         cseed, _ptr(centres), _ptr(self.assign), _ptr(self.state),
-                                         _ptr(self.stats), _ptr(self.bbox), _ptr(self.n_big),
-                                         int(max_rounds), _stream()))
+            fn = lib.imgan_dcd_segments_boxed if boxed else lib.imgan_dcd_segments
+            check(fn(_ptr(lab), _ptr(labels), *shape, 1 if use_hash else 0, cseed, _ptr(centres),
+                     _ptr(self.assign), _ptr(self.state), _ptr(self.stats), _ptr(self.bbox),
+                     _ptr(self.n_big), int(max_rounds), _stream()))
             self.big_segments = int(self.n_big.item())
         self.rounds_run = 0
         if self.big_segments == 0:

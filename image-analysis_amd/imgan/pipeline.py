@@ -46,13 +46,16 @@ class FullPipeline(object):
     def run_slic(self, bgr, timed=False):
         self._timed("bgr2lab", timed, lambda: ops.bgr2lab(bgr, out=self.lab))
         self.slic.init(self.lab)
-        for _ in range(1, self.num_iter):
+        for it in range(1, self.num_iter):
+            # the last round also leaves the bounding boxes of the superpixels for run_dcd
+            box = self.dcd.bbox if (it == self.num_iter - 1 and self.dcd is not None) else None
             if timed:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                self.slic.round(self.lab, self.cw, events=ev)
+                self.slic.round(self.lab, self.cw, events=ev, bbox=box)
                 self.stage_events.setdefault("slic_assign", []).append(ev)
             else:
-                self.slic.round(self.lab, self.cw)
+                self.slic.round(self.lab, self.cw, bbox=box)
+        self.boxed = self.dcd is not None and self.num_iter > 1
         return self.slic.labels
 
     def run_dcd(self, timed=False):
@@ -61,7 +64,8 @@ class FullPipeline(object):
 
         def go():
             self.dcd.kmeans(self.lab, labels, self.centres, seed=self.seed,
-                            max_rounds=self.max_rounds, check_every=self.check_every)
+                            max_rounds=self.max_rounds, check_every=self.check_every,
+                            boxed=getattr(self, "boxed", False))
             self.dcd_rounds_run = self.dcd.rounds_run
             stats = self.dcd.statistics(self.lab, labels)
             check(lib.imgan_dcd_features(p(stats), p(self.centres), self.B, self.n, self.k,

@@ -77,6 +77,14 @@ int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int
                                  int n, double colour_weight, void* workspace,
                                  imgan_stream_t stream);
 
+/* The same, and the bounding box of every label of the updated map on the side (slic.py has no
+ * counterpart; the callers take them per segment with cv2.boundingRect, spatialextract.py:47,
+ * or np.where, mpeg7Descriptors.py:28-33): bbox_out int32 [B][n][4] = xmin, ymin, xmax, ymax,
+ * a label without pixels gets {INT_MAX, INT_MAX, -1, -1} as in imgan_label_bbox. */
+int imgan_slic_assign_accumulate_bbox(const uint8_t* lab, int32_t* labels, int B, int H, int W,
+                                      int S, int n, double colour_weight, void* workspace,
+                                      int32_t* bbox_out, imgan_stream_t stream);
+
 /* slic.py:124-126: centre = floor(sum / count), empty cluster -> 0. */
 int imgan_slic_finalise_centres(int32_t* centres, int B, int H, int W, int S, int n,
                                 void* workspace, imgan_stream_t stream);
@@ -180,6 +188,16 @@ int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int B, int H, 
                        int k, int use_hash_init, uint32_t seed, float* centres, uint8_t* assign,
                        void* state, uint64_t* stats, void* bbox_scratch, int32_t* n_big_out,
                        int max_rounds, imgan_stream_t stream);
+
+/* The same with the bounding boxes already in place: the first B * nseg * 16 bytes of
+ * bbox_scratch hold int32 [B][nseg][4] = xmin, ymin, xmax, ymax of every segment of `labels`
+ * (imgan_label_bbox, or imgan_slic_assign_accumulate_bbox when the labels are superpixels),
+ * which saves the pass over the label map that finds them (segment_generator's
+ * np.where(clusters == seg), mpeg7Descriptors.py:28-33, for every segment at once). */
+int imgan_dcd_segments_boxed(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
+                             int nseg, int k, int use_hash_init, uint32_t seed, float* centres,
+                             uint8_t* assign, void* state, uint64_t* stats, void* bbox_scratch,
+                             int32_t* n_big_out, int max_rounds, imgan_stream_t stream);
 
 /* mpeg7Descriptors.py:114-129 from the integer statistics: features float32 [B][nseg][k][8] =
  * mean(3), population variance(3), percentage, spatial coherence. */

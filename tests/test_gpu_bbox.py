@@ -1,0 +1,92 @@
+"""Bounding boxes of the superpixels as a by-product of the last SLIC round
+(imgan_slic_assign_accumulate_bbox) and the dominant-colour kernel that takes them
+(imgan_dcd_segments_boxed): both against the stand-alone pass over the label map."""
+import numpy as np
+import pytest
+
+from conftest import voronoi_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes_numpy(labels, n):
+    out = np.empty((n, 4), np.int32)
+    out[:, :2] = 0x7fffffff
+    out[:, 2:] = -1
+    ys, xs = np.nonzero(labels >= 0)
+    lb = labels[ys, xs]
+    np.minimum.at(out[:, 0], lb, xs)
+    np.minimum.at(out[:, 1], lb, ys)
+    np.maximum.at(out[:, 2], lb, xs)
+    np.maximum.at(out[:, 3], lb, ys)
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,K,cw", [
+    (2, 213, 320, 200, 15),      # S = 18: 4 rows per lane
+    (1, 270, 480, 100, 10),      # S = 36: 8 rows per lane, one band per tile
+    (2, 200, 260, 16, 15),       # S = 57: two bands per tile
+    (1, 203, 259, 16, 15),       # unaligned rows
+    (1, 96, 128, 12, 40.5),      # non-integral colour weight: literal float64 key path
+    (1, 64, 64, 256, 15),        # S = 4: more centres than a tile record holds (slow tile path)
+])
+def test_slic_round_boxes_equal_label_map_boxes(B, H, W, K, cw):
+    import ctypes
+    import torch
+    from imgan import ops
+    from imgan._lib import lib, check
+    img = np.stack([voronoi_image(H, W, max(4, min(K, 64)), seed=50 + b) for b in range(B)])
+    lab = ops.bgr2lab(torch.from_numpy(img).cuda())
+    plan = ops.SlicPlan(B, H, W, K)
+    box = torch.full((B, plan.n, 4), 12345, dtype=torch.int32, device="cuda")
+    plan.init(lab)
+    for it in range(3):
+        plan.round(lab, cw, bbox=box if it == 2 else None)
+    labels = plan.labels.cpu().numpy()
+    got = box.cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got[b], _boxes_numpy(labels[b], plan.n)), b
+    # and the stand-alone kernel agrees
+    ref = torch.empty_like(box)
+    check(lib.imgan_label_bbox(ops._ptr(plan.labels), B, H, W, plan.n, ops._ptr(ref), ops._stream()))
+    assert torch.equal(ref, box)
+
+
+def test_boxes_follow_pixels_that_keep_their_label():
+    """A pixel no window reaches in the last round keeps its label (slic.py:81,113) and still
+    counts for the box of that label."""
+    import torch
+    from imgan import ops
+    H, W, K = 120, 160, 12
+    img = voronoi_image(H, W, 6, seed=9)
+    lab = ops.bgr2lab(torch.from_numpy(img[None]).cuda())
+    plan = ops.SlicPlan(1, H, W, K)
+    plan.init(lab)
+    plan.round(lab, 15)
+    # move every centre into one corner: most of the image is out of reach of every window
+    plan.centres[:, :, 3] = 3
+    plan.centres[:, :, 4] = 3
+    box = torch.empty((1, plan.n, 4), dtype=torch.int32, device="cuda")
+    before = plan.labels.clone()
+    plan.round(lab, 15, bbox=box)
+    labels = plan.labels.cpu().numpy()[0]
+    assert (labels == before.cpu().numpy()[0]).mean() > 0.5          # most pixels kept their label
+    assert np.array_equal(box.cpu().numpy()[0], _boxes_numpy(labels, plan.n))
+
+
+def test_dominant_colours_with_given_boxes_equal_the_plain_call():
+    import torch
+    from imgan.pipeline import FullPipeline
+    B, H, W, K = 3, 216, 384, 60
+    img = np.stack([voronoi_image(H, W, 20, seed=70 + b) for b in range(B)])
+    bgr = torch.from_numpy(img).cuda()
+    pipe = FullPipeline(B, H, W, K)
+    pipe.run_slic(bgr)
+    assert pipe.boxed
+    pipe.run_dcd()
+    feats, assign = pipe.features.clone(), pipe.dcd.assign.clone()
+    stats = pipe.dcd.stats.clone()
+    pipe.boxed = False                                  # the kernel finds the boxes itself
+    pipe.run_dcd()
+    assert torch.equal(pipe.dcd.stats, stats) and torch.equal(pipe.dcd.assign, assign)
+    assert torch.equal(pipe.features.view(torch.int32), feats.view(torch.int32))
