@@ -876,9 +876,10 @@ AssignParams make_params(int B, int H, int W, int S, int n, double colour_weight
     P.cw2 = *mode_out == 2 ? 0u : (unsigned)(colour_weight * colour_weight);
     P.nsub = L.nsub;
     P.ntiles = (long long)B * L.ntx * L.nty;
-    // LDS is sized for about twice the expected number of centres around a tile
+    // LDS is sized for about 1.5 times the expected number of centres around a tile (a tile that
+    // sees more takes the slow path): every 4 KB less is another workgroup per CU
     double m_est = (double)(TW + 2 * S) * (L.tile_h + 2 * S) / ((double)S * S);
-    P.maxc = std::min(MAXC, std::max(16, ((int)(2.0 * m_est) + 4 + 7) / 8 * 8));
+    P.maxc = std::min(MAXC, std::max(16, ((int)(1.5 * m_est) + 4 + 7) / 8 * 8));
     P.bbox = nullptr;
     return P;
 }
