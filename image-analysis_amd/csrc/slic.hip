@@ -374,8 +374,11 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     return r;
 }
 
+// 7 waves per SIMD: what the LDS of the common configurations allows (one workgroup = one wave
+// per SIMD); without the hint the compiler settles on 77 registers, one wave short of that
+#define IMGAN_ASSIGN_WAVES __attribute__((amdgpu_waves_per_eu(7, 7)))
 template <int MODE, bool ALIGNED, bool REL, int R>
-__global__ __launch_bounds__(256) void slic_assign_kernel(const uint8_t* __restrict__ lab,
+__global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(const uint8_t* __restrict__ lab,
                                                           int32_t* __restrict__ labels, Ws w,
                                                           AssignParams P) {
     // dynamic LDS, sized by the host for the number of centres a tile is expected to see
