@@ -376,7 +376,9 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 
 // 7 waves per SIMD: what the LDS of the common configurations allows (one workgroup = one wave
 // per SIMD); without the hint the compiler settles on 77 registers, one wave short of that
+#ifndef IMGAN_ASSIGN_WAVES
 #define IMGAN_ASSIGN_WAVES __attribute__((amdgpu_waves_per_eu(7, 7)))
+#endif
 template <int MODE, bool ALIGNED, bool REL, int R>
 __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(const uint8_t* __restrict__ lab,
                                                           int32_t* __restrict__ labels, Ws w,
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
     uint32_t* tr = acc + maxc * 192;                            // [wave][row][column] transposition
     // bounding boxes of the new labels (P.bbox, last round only): the columns of a slot are the
     // lanes whose count is not zero; its rows come from a lane-private min / max pair
-    uint32_t* ybox = tr + 4 * R * 64;                           // [slot][min, max][lane]
+    uint32_t* ybox = tr + 4 * 4 * 64;                           // [slot][min, max][lane]
     int* const bbox = P.bbox;                                   // wave uniform
 
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2),
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
 
     const int twoS = 2 * S;
     const int nS2x2 = -2 * (int)P.S2;
-    uint32_t* trw = tr + wave * (R * 64);
+    uint32_t* trw = tr + wave * (4 * 64);                // 4 rows at a time
     for (int sub = 0; sub < nsub; ++sub) {
         const int wy0 = sub * BAND + wave * R;           // tile relative first row of this wave
         if (y0 + wy0 >= H - 1) continue;                 // whole wave below the image
@@ -527,13 +529,13 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                     if (sub == k) v = raw[k][g];
                 uint32_t q[4];
                 unpack(v, q);
-                *reinterpret_cast<uint4*>(trw + (g * 4 + (lane >> 4)) * 64 + (lane & 15) * 4) =
+                *reinterpret_cast<uint4*>(trw + (lane >> 4) * 64 + (lane & 15) * 4) =
                     make_uint4(q[0], q[1], q[2], q[3]);
-            }
-            __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < R; ++j) px[j] = trw[j * 64 + lane];
-            __builtin_amdgcn_wave_barrier();
+                for (int r = 0; r < 4; ++r) px[g * 4 + r] = trw[r * 64 + lane];
+                __builtin_amdgcn_wave_barrier();
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < R; ++j) {
@@ -928,7 +930,7 @@ static int assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H, 
     bool aligned = (W % 4 == 0) && (((uintptr_t)lab & 3) == 0) && (((uintptr_t)labels & 15) == 0);
     const int rows = choose_rows(S);
     size_t lds_bytes = (size_t)P.maxc * (sizeof(int4) + 3 * 64 * sizeof(uint32_t)) +
-                       (size_t)4 * rows * 64 * 4;
+                       (size_t)4 * 4 * 64 * 4;
     IMGAN_REQUIRE((P.ntiles + 7) / 8 * 8 < 0x7fffffffLL, "imgan_slic_assign_accumulate: too many tiles");
     dim3 grid((unsigned)((P.ntiles + 7) / 8 * 8));
     hipStream_t st = (hipStream_t)stream;
