@@ -114,3 +114,36 @@ def test_slic_rejects_non_array():
     from slic import SLICSuperPixel
     with pytest.raises(ValueError):
         SLICSuperPixel(None, 10)
+
+
+@pytest.mark.parametrize("kind", ["flat", "blocks", "quantised", "gradient"])
+@pytest.mark.parametrize("K,cw", [(12, 15), (24, 1), (20, 40)])
+def test_slic_exact_ties_large_step(kind, K, cw):
+    """Images built to produce equal keys (flat areas, few colours, mirror symmetry) at steps
+    that take the 8-rows-per-lane, two-band tiles: the second-lowest-key tracking and the
+    float64 replay must leave exactly the reference's labels.  Oracle: the C restatement
+    (bit-identical to the numpy oracle, tests/test_oracle_c.py; the numpy one needs minutes)."""
+    torch = _torch()
+    from imgan import ops
+    from oracle import c_oracle
+    from oracle.color import bgr2lab_u8
+    H, W = 240, 320
+    rng = np.random.RandomState(K + int(cw))
+    if kind == "flat":
+        img = np.full((H, W, 3), 77, np.uint8)
+    elif kind == "blocks":
+        img = np.zeros((H, W, 3), np.uint8)
+        img[(np.arange(H)[:, None] // 40 + np.arange(W)[None, :] // 40) % 2 == 1] = (200, 120, 40)
+    elif kind == "quantised":
+        img = (voronoi_image(H, W, 30, seed=K) // 64 * 64).astype(np.uint8)
+    else:
+        img = np.empty((H, W, 3), np.uint8)
+        img[...] = (np.arange(W)[None, :, None] // 16 * 12).astype(np.uint8)    # mirror-free ramps
+        img[:, W // 2:] = img[:, :W // 2][:, ::-1]                                # and a mirror
+    lab = bgr2lab_u8(img)
+    want_labels, want_centres = c_oracle.slic_run(lab, K, cw, 6)
+    plan = ops.SlicPlan(1, H, W, K)
+    labels, centres = plan.run(torch.from_numpy(lab[None]).cuda(), cw, 6)
+    assert plan.S >= 48
+    assert np.array_equal(labels.cpu().numpy()[0], want_labels)
+    assert np.array_equal(centres.cpu().numpy()[0], want_centres)
