@@ -88,6 +88,39 @@ def test_dominant_colour_matches_oracle(H, W, K, k):
                 assert np.allclose(gv, wv, rtol=1e-4, atol=1e-9), (seg, j, gv, wv)
 
 
+@pytest.mark.parametrize("levels", [64, 128])
+def test_dominant_colour_exact_ties(levels):
+    """Few distinct colours per segment: initial centres coincide (equal distances for every
+    pixel, the lower cluster index must win and the other stays empty) and pixels sit at equal
+    distance from two centres, so the near-tie replay of the fast loop decides most pixels."""
+    torch = _torch()
+    from mpeg7Descriptors import MPEG7Descriptors
+    from oracle.dcd_ref import DCDOracle
+    H, W, k = 96, 160, 6
+    img = (voronoi_image(H, W, 40, seed=levels, noise=0.0) // levels * levels).astype(np.uint8)
+    clusters = (np.arange(W)[None, :] // 40 + 0 * np.arange(H)[:, None]).astype(np.float64)
+    rng = np.random.RandomState(levels)
+    init = {seg: sorted(rng.choice(H * 40, k, replace=False).tolist()) for seg in range(4)}
+    mp = MPEG7Descriptors(clusters, img)
+    got = mp.mpeg7_dominant_colours(k, init=init)
+    ora = DCDOracle(clusters, img)
+    want = ora.mpeg7_dominant_colours(k, lambda seg, n, kk: init[seg])
+    empties = 0
+    for seg in want:
+        assert mp.dcd_rounds[seg] == ora.rounds[seg], seg
+        for j in range(k):
+            gm, gv, gp, gc = got[seg][j]
+            wm, wv, wp, wc = want[seg][j]
+            assert np.allclose(gm, wm, rtol=1e-6, atol=0), (seg, j, gm, wm)
+            assert gp == wp and gc == wc, (seg, j, gp, wp, gc, wc)
+            if np.isnan(wv).any():
+                empties += 1
+                assert np.isnan(gv).all()
+            else:
+                assert np.allclose(gv, wv, rtol=1e-6, atol=1e-9), (seg, j, gv, wv)
+    assert empties > 0                                   # coinciding centres did occur
+
+
 def test_dominant_colour_single_segment_api():
     torch = _torch()
     from mpeg7Descriptors import MPEG7Descriptors
