@@ -225,10 +225,10 @@ __global__ __launch_bounds__(256) void slic_tiles_kernel(Ws w, AssignParams P) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ntiles = w.ntx * w.nty;
     const long long t = (long long)blockIdx.x * 4 + wv;
-    const bool live = t < (long long)B * ntiles;
+    if (t >= (long long)B * ntiles) return;              // wave uniform
     int m = 0;
     int b = 0, x0 = 0, y0 = 0;
-    if (live) {
+    {
         b = (int)(t / ntiles);
         const int ti = (int)(t - (long long)b * ntiles);
         const int ty = ti / w.ntx, tx = ti - ty * w.ntx;
@@ -240,25 +240,53 @@ __global__ __launch_bounds__(256) void slic_tiles_kernel(Ws w, AssignParams P) {
         const int cyl = max(y0 - S + 1, 0) / S, cyh = min((y1 + S) / S, w.ncy - 1);
         const int4* scand = w.scand + (size_t)b * n;
         const int* start = w.start + (size_t)b * (w.ncell + 1);
-        for (int cyc = cyl; cyc <= cyh; ++cyc) {
-            const int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
-            for (int i0 = beg; i0 < end; i0 += 64) {
-                const int i = i0 + lane;
-                bool hit = false;
-                int4 q = make_int4(0, 0, 0, 0);
-                if (i < end) {
-                    q = scand[i];
-                    hit = q.x >= x0 - S + 1 && q.x <= x1 + S && q.y >= y0 - S + 1 && q.y <= y1 + S;
+        auto take = [&](int i, bool valid) {
+            bool hit = false;
+            int4 q = make_int4(0, 0, 0, 0);
+            if (valid) {
+                q = scand[i];
+                hit = q.x >= x0 - S + 1 && q.x <= x1 + S && q.y >= y0 - S + 1 && q.y <= y1 + S;
+            }
+            const unsigned long long vote = __ballot(hit);
+            const int slot = m + __popcll(vote & ((1ull << lane) - 1ull));
+            if (hit && slot < MAXC) u_c[wv][slot] = q;
+            m += __popcll(vote);
+        };
+        const int nrow = cyh - cyl + 1;
+        if (nrow <= 8) {
+            // Two memory round trips for the whole tile: lane r fetches the bounds of cell row r,
+            // then the candidates of all rows are spread over the lanes (a loop over the rows
+            // would pay two dependent round trips per row).
+            int myb = 0, mye = 0;
+            if (lane < nrow) {
+                myb = start[(cyl + lane) * w.ncx + cxl];
+                mye = start[(cyl + lane) * w.ncx + cxh + 1];
+            }
+            int rb[8], rc[8], total = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                rb[r] = __shfl(myb, r);
+                rc[r] = __shfl(mye, r) - rb[r];
+                total += rc[r];
+            }
+            for (int l0 = 0; l0 < total; l0 += 64) {
+                const int l = l0 + lane;
+                int i = 0, acc = 0;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (l >= acc && l < acc + rc[r]) i = rb[r] + (l - acc);
+                    acc += rc[r];
                 }
-                const unsigned long long vote = __ballot(hit);
-                const int slot = m + __popcll(vote & ((1ull << lane) - 1ull));
-                if (hit && slot < MAXC) u_c[wv][slot] = q;
-                m += __popcll(vote);
+                take(i, l < total);
+            }
+        } else {
+            for (int cyc = cyl; cyc <= cyh; ++cyc) {
+                const int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
+                for (int i0 = beg; i0 < end; i0 += 64) take(i0 + lane, i0 + lane < end);
             }
         }
     }
-    __syncthreads();
-    if (!live) return;
+    __builtin_amdgcn_wave_barrier();                     // u_c[wv] belongs to this wave alone
     int8v* rec = w.tiles + (size_t)t * TILE_REC;
     if (lane == 0) {
         int8v h = {m, x0, y0, 0, 0, 0, 0, 0};
