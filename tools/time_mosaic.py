@@ -24,3 +24,15 @@ print("big segments", dcd.big_segments, "streaming rounds", dcd.rounds_run)
 stats = dcd.statistics(lab, labels); t = tick("dcd stats", t)
 sums, edges = ops.rag_accumulate(lab, labels, K); t = tick("rag accumulate+edges", t)
 print("edges", len(edges[0]))
+# where the adjacency time goes
+t = time.perf_counter()
+ops.rag_accumulate(lab, labels, K, want_edges=False); t = tick("rag sums only", t)
+for _ in range(2):
+    ops.rag_accumulate(lab, labels, K); t = tick("rag accumulate+edges again", t)
+cap = 1 << 20
+table = torch.zeros((1, cap), dtype=torch.int64, device="cuda"); ovf = torch.zeros(1, dtype=torch.int32, device="cuda")
+s2 = torch.zeros((1, K, 4), dtype=torch.int64, device="cuda"); t = tick("alloc", t)
+from imgan._lib import lib, check
+check(lib.imgan_rag_accumulate(ops._ptr(lab), ops._ptr(labels), 1, H, W, K, ops._ptr(s2), ops._ptr(table), cap, ops._ptr(ovf), ops._stream())); t = tick("kernel with edge set", t)
+o, _ = torch.sort(table, dim=1); t = tick("sort", t)
+h = o.cpu().numpy(); t = tick("transfer", t)
