@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int maxc = P.maxc;
     int4* s_c = reinterpret_cast<int4*>(smem);                  // by rank: {cx', cy', lab, idx}
-    uint32_t* acc = reinterpret_cast<uint32_t*>(s_c + maxc);    // [slot][word][lane] partial sums
+    uint32_t* acc = reinterpret_cast<uint32_t*>(s_c + MAXC);    // [maxc slots][word][lane] partial sums
     uint32_t* tr = acc + maxc * 192;                            // [wave][row][column] transposition
     // bounding boxes of the new labels (P.bbox, last round only): the columns of a slot are the
     // lanes whose count is not zero; its rows come from a lane-private min / max pair
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
     const int8v* recv = w.tiles + (size_t)tile * TILE_REC;
     const int8v AS_CONST* rec = (const int8v AS_CONST*)recv;
     const int m = rec[0][0];
-    if (tid < m && m <= maxc) {
+    if (tid < m && m <= MAXC) {
         const int8v e = recv[1 + tid];
         s_c[tid] = make_int4(e[0], e[1], e[2], e[3]);
     }
@@ -486,8 +486,12 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
     const int x = x0 + xr;
     const bool colok = x < W - 1;
 
-    if (m > maxc) {
-        // ---- slow path: too many centres around this tile (degenerate inputs).  Every lane
+    // A tile that sees more centres than the LDS accumulators were sized for (maxc) still takes
+    // the fast loop: its record holds up to MAXC entries, and only the pixels won by a slot
+    // beyond maxc go to global memory one by one.
+    const int macc = min(m, maxc);                         // slots with LDS accumulators
+    if (m > MAXC) {
+        // ---- slow path: more centres around this tile than a record holds (steps of a few pixels).  Every lane
         // walks the cell lists itself for one pixel at a time and flushes with global atomics.
         const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + w.tile_h - 1, H - 2);
         const int4* scand = w.scand + (size_t)b * n;
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
 #pragma unroll
         for (int j = 1; j < R; ++j) lowest = min(lowest, slot[j]);
         const bool rows_full = y0 + wy0 + R <= H - 1;
-        if (rows_full && __builtin_amdgcn_ballot_w64(colok && lowest < 0) == 0ull) {
+        if (rows_full && m <= maxc && __builtin_amdgcn_ballot_w64(colok && lowest < 0) == 0ull) {
             // the common case, free of per-row branches: every pixel of the wave has a centre
             if (colok) {
                 int lbl[R];
@@ -730,7 +734,12 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
             for (int j = 0; j < R; ++j, lrow += W) {
                 const int yr = wy0 + j, y = y0 + yr;
                 if (!(y < H - 1 && colok)) continue;
-                if (slot[j] >= 0) {
+                if (slot[j] >= maxc) {                // no LDS accumulator for this slot
+                    const int lbl = s_c[slot[j]].w;
+                    *lrow = lbl;
+                    flush_pixel_global(sums, lbl, px[j], x, y);
+                    if (bbox) bbox_point_global(bbox + ((size_t)b * n + lbl) * 4, x, y, x, y);
+                } else if (slot[j] >= 0) {
                     *lrow = s_c[slot[j]].w;
                     const uint32_t p = px[j];
                     uint32_t* a = acc + (__mul24(slot[j], 192) + lane);
@@ -758,9 +767,9 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
     // its 3 packed rows (L|a, b|count, x'|y'), 16 copies per lane.  A copy holds at most
     // 4 waves x nsub bands x R rows = tile height <= 64 pixels, so its 16-bit halves cannot overflow
     // (64 * 255 < 65536); the halves are widened before they are summed.
-    for (int s0 = 0; s0 < m; s0 += 16) {
+    for (int s0 = 0; s0 < macc; s0 += 16) {
         const int s = s0 + (tid >> 4), r = (tid >> 2) & 3, q = tid & 3;
-        const bool live = s < m && r < 3;
+        const bool live = s < macc && r < 3;
         uint32_t lo = 0, hi = 0;
         if (live) {
             const uint4* src = reinterpret_cast<const uint4*>(acc + (s * 3 + r) * 64 + q * 16);
@@ -794,10 +803,10 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
         // 16 lanes per slot, 4 columns per lane: the columns that hold the slot (count != 0)
         // give the x range directly, their row extremes the y range; one global update per
         // (tile, slot) and bound
-        for (int s0 = 0; s0 < m; s0 += 16) {
+        for (int s0 = 0; s0 < macc; s0 += 16) {
             const int s = s0 + (tid >> 4), t16 = tid & 15;
             int xa = 0x7fffffff, ya = 0x7fffffff, xb = -1, yb = -1;
-            if (s < m) {
+            if (s < macc) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int col = 4 * t16 + c;
@@ -816,7 +825,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                 xb = max(xb, __shfl_xor(xb, o));
                 yb = max(yb, __shfl_xor(yb, o));
             }
-            if (s < m && t16 == 0 && xb >= 0)
+            if (s < macc && t16 == 0 && xb >= 0)
                 bbox_point_global(bbox + ((size_t)b * n + s_c[s].w) * 4, x0 + xa, y0 + ya, x0 + xb,
                                   y0 + yb);
         }
@@ -957,7 +966,7 @@ static int assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H, 
     AssignParams P = make_params(B, H, W, S, n, colour_weight, L, &mode, &rel);
     bool aligned = (W % 4 == 0) && (((uintptr_t)lab & 3) == 0) && (((uintptr_t)labels & 15) == 0);
     const int rows = choose_rows(S);
-    size_t lds_bytes = (size_t)P.maxc * (sizeof(int4) + 3 * 64 * sizeof(uint32_t)) +
+    size_t lds_bytes = (size_t)MAXC * sizeof(int4) + (size_t)P.maxc * 3 * 64 * sizeof(uint32_t) +
                        (size_t)4 * 4 * 64 * 4;
     IMGAN_REQUIRE((P.ntiles + 7) / 8 * 8 < 0x7fffffffLL, "imgan_slic_assign_accumulate: too many tiles");
     dim3 grid((unsigned)((P.ntiles + 7) / 8 * 8));

@@ -90,3 +90,47 @@ def test_dominant_colours_with_given_boxes_equal_the_plain_call():
     pipe.run_dcd()
     assert torch.equal(pipe.dcd.stats, stats) and torch.equal(pipe.dcd.assign, assign)
     assert torch.equal(pipe.features.view(torch.int32), feats.view(torch.int32))
+
+
+def test_crowded_tile_takes_the_fast_loop_with_global_overflow_slots():
+    """More centres reach one tile than its LDS accumulators were sized for (but no more than a
+    tile record holds): the pixels won by the slots beyond go to global memory one by one.
+    Labels against a brute-force evaluation of the exact key, centres against the label map,
+    boxes against the label map."""
+    import torch
+    from imgan import ops
+    from test_gpu_fullsize import _brute_force_labels, _segment_sums
+    H, W, K, cw = 240, 320, 48, 15
+    img = voronoi_image(H, W, 30, seed=3)
+    lab = ops.bgr2lab(torch.from_numpy(img[None]).cuda())
+    plan = ops.SlicPlan(1, H, W, K)
+    n, S = plan.n, plan.S
+    assert n == 35 and S == 40
+    plan.init(lab)
+    plan.round(lab, cw)
+    before = plan.labels.clone()
+    # every centre into a 40 x 30 patch: the tiles around it see all 35 of them
+    idx = torch.arange(n, device="cuda")
+    plan.centres[0, :, 3] = (100 + (idx % 7) * 6).int()
+    plan.centres[0, :, 4] = (80 + (idx // 7) * 6).int()
+    prev = plan.centres[0].clone()
+    box = torch.empty((1, n, 4), dtype=torch.int32, device="cuda")
+    plan.round(lab, cw, bbox=box)
+    labels = plan.labels[0]
+    ys, xs = torch.meshgrid(torch.arange(H - 1, device="cuda"), torch.arange(W - 1, device="cuda"),
+                            indexing="ij")
+    want, tie = _brute_force_labels(torch, lab[0], prev, S, cw, xs.reshape(-1), ys.reshape(-1))
+    got = labels[:H - 1, :W - 1].reshape(-1).long()
+    kept = before[0, :H - 1, :W - 1].reshape(-1).long()
+    expect = torch.where(want == -2, kept, want)
+    assert int(((got != expect) & ~tie).sum()) == 0
+    assert int((want != -2).sum()) > 5000                    # the crowded tiles were exercised
+    lb = labels.reshape(-1)
+    ok = lb >= 0
+    yy, xx = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+    vals = [lab[0, :, :, c].reshape(-1)[ok] for c in range(3)] + [xx.reshape(-1)[ok], yy.reshape(-1)[ok]]
+    cnt, sums = _segment_sums(torch, lb[ok], vals, n)
+    for f, s in enumerate(sums):
+        wantc = torch.where(cnt > 0, s // cnt.clamp(min=1), torch.zeros_like(s))
+        assert torch.equal(wantc.int(), plan.centres[0, :, f]), f
+    assert np.array_equal(box.cpu().numpy()[0], _boxes_numpy(labels.cpu().numpy(), n))
