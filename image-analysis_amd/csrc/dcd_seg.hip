@@ -52,6 +52,7 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;   // one global_load
 // Lloyd rounds are latency bound per workgroup, and wave counts that do not divide by four leave
 // one SIMD holding the others up at every barrier.
 constexpr int CAP_SMALL = 11520, THREADS_SMALL = 768;       // 6 B of LDS per pixel
+constexpr int CAP_SMALL_K16 = 10752;   // 9 .. 16 colours: twice the accumulators, still two workgroups per CU
 constexpr int CAP_LARGE = 22528, THREADS_LARGE = 1024;     // >= 4 S^2 of the 1080p / K=400 grid
 // The small tier packs {count, sum0} and {sum1, sum2} into 16-bit halves of two words per
 // lane-private copy: a copy sees at most CAP / 64 pixels, and 180 * 255 < 65536.
@@ -796,7 +797,7 @@ static int dcd_segments(const uint8_t* lab, const int32_t* labels, int B, int H,
         TIER(8, CAP_SMALL, THREADS_SMALL, true)
         TIER(8, CAP_LARGE, THREADS_LARGE, false)
     } else {
-        TIER(16, CAP_SMALL, THREADS_SMALL, true)
+        TIER(16, CAP_SMALL_K16, THREADS_SMALL, true)
         TIER(16, CAP_LARGE, THREADS_LARGE, false)
     }
 #undef TIER

@@ -265,14 +265,15 @@ def test_full_pipeline_batch_matches_oracle():
                 assert np.isclose(g[6], wp, rtol=1e-6) and np.isclose(g[7], wc, rtol=1e-6)
 
 
-def test_dcd_lds_path_equals_streaming_path():
+@pytest.mark.parametrize("k", [8, 12])
+def test_dcd_lds_path_equals_streaming_path(k):
     """The LDS-resident segment kernel and the streaming rounds are two schedules of the same
     arithmetic: centres, assignment, statistics and round counts must be identical, also when
     some segments are too large for LDS and take the streaming rounds."""
     torch = _torch()
     from imgan import ops
     from oracle.color import bgr2lab_u8
-    H, W, k = 200, 260, 8
+    H, W = 200, 260
     img = voronoi_image(H, W, 14, seed=61, noise=15.0)
     lab = torch.from_numpy(bgr2lab_u8(img)).cuda().unsqueeze(0)
     # 30 small square segments + one large segment (> LDS capacity) + unlabelled border
