@@ -21,10 +21,17 @@
 
 namespace {
 
+// Sum over the 64 lanes with data-parallel-primitive adds (one vector instruction per step, no
+// LDS traffic): four shifts inside the rows of 16 lanes, then lane 15 of rows 0 / 2 into rows
+// 1 / 3 and lane 31 into rows 2 / 3.  The total is lane 63's value, returned to every lane.
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ uint32_t hash64(unsigned long long k) {
@@ -53,56 +60,76 @@ __device__ void edge_insert(unsigned long long* tab, unsigned long long mask, in
     *overflow = 1;
 }
 
-// one thread per pixel, rows of the image; block = 256 consecutive pixels of one image
+typedef uint32_t __attribute__((aligned(1))) u32_any;   // one global_load_dword at any address
+constexpr int RAG_ROWS = 16;
+
+// one lane per column; block = 256 columns x RAG_ROWS rows (grid: column strips, row strips, images)
 __global__ __launch_bounds__(256) void rag_accumulate_kernel(
     const uint8_t* __restrict__ img, const int32_t* __restrict__ labels, int H, int W, int K,
     unsigned long long* __restrict__ sums, unsigned long long* __restrict__ edges,
-    unsigned long long edge_mask, int* __restrict__ overflow) {
-    const int b = blockIdx.y;
+    unsigned long long edge_mask, int* __restrict__ overflow, long long last_px) {
+    const int b = blockIdx.z;
     const long long npix = (long long)H * W;
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int x = blockIdx.x * 256 + threadIdx.x;
     const int32_t* lab = labels + (size_t)b * npix;
     const uint8_t* im = img + (size_t)b * npix * 3;
     unsigned long long* S = sums + (size_t)b * K * 4;
     unsigned long long* E = edges ? edges + (size_t)b * (edge_mask + 1) : nullptr;
-
+    // RAG_ROWS rows per block: one row per block leaves the launch bound by the workgroup
+    // dispatch rate (a row of 256 pixels is a few hundred cycles of work).  A lane keeps the sums
+    // of the label it is walking down in registers; when lanes change label (typically a whole
+    // run of lanes crossing a region border together) the old label's sums of those lanes are
+    // added up over the wave and leave with one atomic per field, as do all sums at the end.
+    int cur = -1;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, an = 0;
+    auto flush = [&](bool who) {
+        int pending = (who && cur >= 0 && cur < K) ? cur : -1;
+        while (true) {
+            const unsigned long long act = __ballot(pending >= 0);
+            if (act == 0ull) break;
+            const int c = __builtin_amdgcn_readlane(pending, __ffsll((long long)act) - 1);
+            const bool mine = (pending == c);
+            // at most 64 lanes x RAG_ROWS rows x 255: far below 2^32
+            const uint32_t t0 = wave_sum(mine ? a0 : 0u), t1 = wave_sum(mine ? a1 : 0u);
+            const uint32_t t2 = wave_sum(mine ? a2 : 0u), tn = wave_sum(mine ? an : 0u);
+            if ((threadIdx.x & 63) == 0) {
+                unsigned long long* s = S + (size_t)c * 4;
+                atomicAdd(&s[0], (unsigned long long)t0);
+                atomicAdd(&s[1], (unsigned long long)t1);
+                atomicAdd(&s[2], (unsigned long long)t2);
+                atomicAdd(&s[3], (unsigned long long)tn);
+            }
+            if (mine) pending = -1;
+        }
+    };
+    const int yend = min((int)(blockIdx.y + 1) * RAG_ROWS, H);
+    for (int y = blockIdx.y * RAG_ROWS; y < yend; ++y) {
+    const long long p = (long long)y * W + x;
     int l = -1;
-    uint32_t c0 = 0, c1 = 0, c2 = 0;
-    int x = 0, y = 0;
-    if (p < npix) {
+    uint32_t raw = 0;
+    if (x < W) {
         l = lab[p];
-        y = (int)(p / W);
-        x = (int)(p - (long long)y * W);
-        if (l >= 0) {
-            const uint8_t* q = im + p * 3;
-            c0 = q[0];
-            c1 = q[1];
-            c2 = q[2];
+        // the three bytes with one (unaligned) dword load; the very last pixel of the batch is
+        // read one byte early so that the load stays inside the buffer
+        const uint32_t sh = ((long long)b * npix + p == last_px) ? 1u : 0u;
+        raw = *reinterpret_cast<const u32_any*>(im + p * 3 - sh) >> (8u * sh);
+    }
+    const bool chg = (l != cur);
+    if (__ballot(chg) != 0ull) {                           // wave uniform
+        flush(chg);
+        if (chg) {
+            cur = l;
+            a0 = a1 = a2 = an = 0;
         }
     }
-    // ---- per-label sums, aggregated over the wave
-    int pending = (l >= 0 && l < K) ? l : -1;
-    while (true) {
-        unsigned long long act = __ballot(pending >= 0);
-        if (act == 0ull) break;
-        int leader = __ffsll((long long)act) - 1;
-        int cur = __shfl(pending, leader);
-        bool mine = (pending == cur);
-        uint32_t w0 = mine ? (c0 | (c1 << 16)) : 0u;      // <= 64 * 255 per half: no overflow
-        uint32_t w1 = mine ? (c2 | (1u << 16)) : 0u;
-        w0 = wave_sum(w0);
-        w1 = wave_sum(w1);
-        if ((int)(threadIdx.x & 63) == leader) {
-            unsigned long long* s = S + (size_t)cur * 4;
-            atomicAdd(&s[0], (unsigned long long)(w0 & 0xffffu));
-            atomicAdd(&s[1], (unsigned long long)(w0 >> 16));
-            atomicAdd(&s[2], (unsigned long long)(w1 & 0xffffu));
-            atomicAdd(&s[3], (unsigned long long)(w1 >> 16));
-        }
-        if (mine) pending = -1;
+    if (l >= 0) {
+        a0 += raw & 0xffu;
+        a1 += (raw >> 8) & 0xffu;
+        a2 += (raw >> 16) & 0xffu;
+        an += 1u;
     }
     // ---- adjacency: E, S, SE, SW neighbours (each unordered 8-neighbour pair once)
-    if (E && l >= 0) {
+    if (E && l >= 0) {                                    // l >= 0 implies x < W
         int last = -1;
         const bool hasS = (y + 1 < H);
         if (x + 1 < W) {
@@ -131,6 +158,8 @@ __global__ __launch_bounds__(256) void rag_accumulate_kernel(
             }
         }
     }
+    }
+    flush(true);
 }
 
 __global__ __launch_bounds__(256) void relabel_kernel(const int32_t* __restrict__ labels,
@@ -214,11 +243,13 @@ extern "C" int imgan_rag_accumulate(const uint8_t* img, const int32_t* labels, i
                       "imgan_rag_accumulate: edge_cap must be a power of two");
         IMGAN_REQUIRE(overflow != nullptr, "imgan_rag_accumulate: overflow flags required");
     }
-    long long npix = (long long)H * W;
-    dim3 grid((unsigned)imgan::cdiv(npix, 256), (unsigned)B);
+    IMGAN_REQUIRE(H <= 65535 * RAG_ROWS, "imgan_rag_accumulate: too many rows");
+    IMGAN_REQUIRE((long long)B * H * W >= 2, "imgan_rag_accumulate: needs at least two pixels");
+    dim3 grid((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, RAG_ROWS), (unsigned)B);
     hipLaunchKernelGGL(rag_accumulate_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, labels,
                        H, W, K, (unsigned long long*)sums, (unsigned long long*)edges,
-                       (unsigned long long)(edges ? edge_cap - 1 : 0), overflow);
+                       (unsigned long long)(edges ? edge_cap - 1 : 0), overflow,
+                       (long long)B * H * W - 1);
     return imgan::check_launch("rag_accumulate_kernel");
 }
 
