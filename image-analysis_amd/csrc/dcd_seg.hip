@@ -371,8 +371,15 @@ __device__ __forceinline__ void segment_body(
         cen[tid] = cen[KM + tid] = cen[2 * KM + tid] = 1.0e18f;
     }
     if (tid == 0) s_done = 0;
-    double old_sum = 0.0;              // only lane 0 of wave 0 uses its copy
+    double old_sum = 0.0;              // only wave 0 uses its copy
     int rounds = 0;
+    // wave 0, lane j < k: centre j and its value one round ago (the serial section of a round)
+    float wc0 = 0.f, wc1 = 0.f, wc2 = 0.f, wo0 = 0.f, wo1 = 0.f, wo2 = 0.f;
+    if (tid < k) {                     // written by this very thread above
+        wc0 = cen[tid];
+        wc1 = cen[KM + tid];
+        wc2 = cen[2 * KM + tid];
+    }
     // a q within 2^-15 of the smallest one replays the literal rule.  What the fast loop leaves
     // out, relative to q, for each of the two values compared: up to 2^-19 for the mantissa bits
     // that carry the cluster index (twice: they are not masked off for the comparison either),
@@ -450,7 +457,91 @@ __device__ __forceinline__ void segment_body(
         }
         __syncthreads();
         SEG_MARK(2)
-        if (wave == 0) {
+        if (wave == 0 && PACKED) {
+            // ---- the serial section of a round, kept in registers: every dependent LDS access
+            // here costs a few hundred cycles under the other workgroup's traffic, and eleven
+            // waves wait for this one.  Reduce the 64 lane-private copies (4 lanes per
+            // (cluster, word) row, 16 copies each; the 4 partial sums of a row meet through two
+            // quad permutes), hand cluster j's {count, sum0} / {sum1, sum2} rows to lane j with
+            // one permute each, and add the shifts up from lane reads.
+            constexpr int ITER = (KM * 2 + 15) / 16;
+            uint32_t lo[ITER], hi[ITER];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int row = it * 16 + (lane >> 2), q = lane & 3;
+                lo[it] = hi[it] = 0;
+                if (row < k * 2) {
+                    uint4* src = reinterpret_cast<uint4*>(acc + row * 64 + q * 16);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint4 w4 = src[t];
+                        src[t] = make_uint4(0, 0, 0, 0);
+                        lo[it] += (w4.x & 0xffffu) + (w4.y & 0xffffu) + (w4.z & 0xffffu) + (w4.w & 0xffffu);
+                        hi[it] += (w4.x >> 16) + (w4.y >> 16) + (w4.z >> 16) + (w4.w >> 16);
+                    }
+                }
+                lo[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[it], 0xb1, 0xf, 0xf, true);   // lanes ^ 1
+                hi[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)hi[it], 0xb1, 0xf, 0xf, true);
+                lo[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[it], 0x4e, 0xf, 0xf, true);   // lanes ^ 2
+                hi[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)hi[it], 0x4e, 0xf, 0xf, true);
+            }
+            // cluster j: rows 2j {count, sum0} and 2j + 1 {sum1, sum2}, i.e. lanes 8 j' and 8 j' + 4
+            // of iteration j / 8 (j' = j % 8)
+            const int srcl = (lane & 7) * 8;
+            uint32_t nj = 0, s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const uint32_t a_ = (uint32_t)__shfl((int)lo[it], srcl), b_ = (uint32_t)__shfl((int)hi[it], srcl);
+                const uint32_t c_ = (uint32_t)__shfl((int)lo[it], srcl + 4), d_ = (uint32_t)__shfl((int)hi[it], srcl + 4);
+                if ((lane >> 3) == it) {
+                    nj = a_;
+                    s0 = b_;
+                    s1 = c_;
+                    s2 = d_;
+                }
+            }
+            SEG_MARK(3)
+            // centre update + stop rule (:93-107); lane j < k holds centre j and its previous value
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            if (lane < k) {
+                red[lane * 4] = nj;                       // the final statistics read these back
+                red[lane * 4 + 1] = s0;
+                red[lane * 4 + 2] = s1;
+                red[lane * 4 + 3] = s2;
+                if (nj) {
+                    const float fn = (float)nj;
+                    wc0 = __fdiv_rn((float)s0, fn);
+                    wc1 = __fdiv_rn((float)s1, fn);
+                    wc2 = __fdiv_rn((float)s2, fn);
+                    cen[lane] = wc0;
+                    cen[KM + lane] = wc1;
+                    cen[2 * KM + lane] = wc2;
+                }
+                a0 = fabsf(__fsub_rn(wc0, wo0));
+                a1 = fabsf(__fsub_rn(wc1, wo1));
+                a2 = fabsf(__fsub_rn(wc2, wo2));
+            }
+            // float32 sums in cluster order (:102), every lane the same
+            float sh0 = 0.f, sh1 = 0.f, sh2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < KM; ++j)
+                if (j < k) {
+                    sh0 = __fadd_rn(sh0, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0), j)));
+                    sh1 = __fadd_rn(sh1, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), j)));
+                    sh2 = __fadd_rn(sh2, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), j)));
+                }
+            const double cent_sum = ((double)sh0 + (double)sh1) + (double)sh2;
+            rounds += 1;
+            const bool stop = fabs(old_sum - cent_sum) < 0.1 || rounds >= max_rounds;
+            if (!stop) {
+                old_sum = cent_sum;
+                wo0 = wc0;
+                wo1 = wc1;
+                wo2 = wc2;
+            } else if (lane == 0) {
+                s_done = rounds;
+            }
+        } else if (wave == 0) {
             // reduce the 64 lane-private copies: 4 lanes per (cluster, word) row, 16 copies each
             for (int row0 = 0; row0 < k * WORDS; row0 += 16) {
                 const int row = row0 + (lane >> 2), q = lane & 3;
