@@ -51,11 +51,11 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;   // one global_load
 // against 512 / 640 / 896 / 1024 threads (5.6 / 6.3 / 8.0 / 7.4 ms where this takes 5.1): the
 // Lloyd rounds are latency bound per workgroup, and wave counts that do not divide by four leave
 // one SIMD holding the others up at every barrier.
-constexpr int CAP_SMALL = 11520, THREADS_SMALL = 768;       // 6 B of LDS per pixel
+constexpr int CAP_SMALL = 12288, THREADS_SMALL = 768;       // 6 B of LDS per pixel
 constexpr int CAP_SMALL_K16 = 10752;   // 9 .. 16 colours: twice the accumulators, still two workgroups per CU
 constexpr int CAP_LARGE = 22528, THREADS_LARGE = 1024;     // >= 4 S^2 of the 1080p / K=400 grid
 // The small tier packs {count, sum0} and {sum1, sum2} into 16-bit halves of two words per
-// lane-private copy: a copy sees at most CAP / 64 pixels, and 180 * 255 < 65536.
+// lane-private copy: a copy sees at most CAP / 64 pixels, and 192 * 255 < 65536.
 static_assert((CAP_SMALL / 64) * 255 < 65536, "packed accumulators would overflow");
 
 // bbox: int [nsegs][4] = xmin, ymin, xmax, ymax.  One block = 256 columns x BBOX_ROWS rows
