@@ -319,6 +319,49 @@ def cc_label(values):
     return roots
 
 
+def enforce_connectivity(labels):
+    """Connectivity enforcement for a superpixel label map (named by the task; scripts/slic.py has
+    no such step, so the rule is this package's own and additive: SLICSuperPixel never applies it
+    unless asked).  Components = 8-connected sets of equal labels, found by the label-propagation
+    union-find kernel (imgan_cc_label).  For every label its largest component stays (ties: the
+    one that starts first in raster order); every other component takes the label of the pixel
+    left of its first raster pixel (above it in column 0), as read from the input map; a
+    component with no labelled pixel there keeps its label.  One pass; unlabelled pixels (-1)
+    stay unlabelled.  labels: int32 [B,H,W] or [H,W] device tensor; returns a new tensor."""
+    _require_gpu()
+    squeeze = labels.dim() == 2
+    if squeeze:
+        labels = labels.unsqueeze(0)
+    _dev(labels, torch.int32, "labels")
+    B, H, W = labels.shape
+    roots = cc_label(labels)
+    out = labels.clone()
+    for b in range(B):                       # the bookkeeping below is per image and tiny next to the kernel
+        lab = labels[b].reshape(-1).long()
+        rt = roots[b].reshape(-1).long()
+        valid = rt >= 0
+        if not bool(valid.any()):
+            continue
+        comp, size = torch.unique(rt[valid], return_counts=True)      # component = its first raster pixel
+        clab = lab[comp]
+        # per label: the largest component, the earliest one among equals
+        order = torch.argsort(comp, stable=True)
+        order = order[torch.argsort(-size[order], stable=True)]
+        order = order[torch.argsort(clab[order], stable=True)]
+        first = torch.ones_like(order, dtype=torch.bool)
+        first[1:] = clab[order][1:] != clab[order][:-1]
+        keep = torch.zeros_like(first)
+        keep[order] = first
+        x0 = comp % W
+        nb = torch.where(x0 > 0, comp - 1, comp - W)                  # left neighbour, else the one above
+        nlab = torch.where(nb >= 0, lab[nb.clamp(min=0)], torch.full_like(nb, -1))
+        new = torch.where(keep | (nlab < 0), clab, nlab)
+        lut = torch.full((H * W,), -1, dtype=torch.long, device=labels.device)
+        lut[comp] = new
+        out[b] = torch.where(valid, lut[rt.clamp(min=0)], lab).view(H, W).int()
+    return out[0] if squeeze else out
+
+
 class DcdPlan(object):
     """Dominant colours of every segment of a label map (mpeg7Descriptors.py:76-130).
 

@@ -110,5 +110,16 @@ class SLICSuperPixel(object):
         cv2.waitKey(0)
         cv2.destroyAllWindows()
 
+    def enforce_connectivity(self):
+        """Additive (not in scripts/slic.py, named by the task): every label keeps its largest
+        8-connected component, the others join the label to their left (imgan.ops.enforce_connectivity:
+        label-propagation union-find on the device).  Updates and returns `clusters`."""
+        if getattr(self, "_dev_labels", None) is None:
+            return self.clusters
+        from imgan import ops
+        self._dev_labels = ops.enforce_connectivity(self._dev_labels)
+        self.clusters = self._dev_labels.cpu().numpy().astype(np.float64)
+        return self.clusters
+
     def get_clusters(self):
         return self.clusters

@@ -160,3 +160,36 @@ class SLICOracle(object):
 
     def get_clusters(self):
         return self.clusters
+
+
+def enforce_connectivity(labels):
+    """The build's own connectivity rule (scripts/slic.py has none; parity unpinned): per label
+    the largest 8-connected component stays (ties: the one whose first raster pixel comes first),
+    every other component takes the label of the pixel left of its first raster pixel (above it
+    in column 0) as read from the input map, or keeps its label when that pixel is unlabelled or
+    missing.  One pass.  Components via scipy.ndimage.label."""
+    from scipy import ndimage
+    labels = np.asarray(labels)
+    H, W = labels.shape
+    out = labels.copy()
+    flat = labels.reshape(-1)
+    eight = np.ones((3, 3), dtype=bool)
+    for l in np.unique(labels):
+        if l < 0:
+            continue
+        comp, ncomp = ndimage.label(labels == l, structure=eight)
+        if ncomp < 2:
+            continue
+        cf = comp.reshape(-1)
+        firsts = np.array([np.flatnonzero(cf == c)[0] for c in range(1, ncomp + 1)])
+        sizes = np.bincount(cf, minlength=ncomp + 1)[1:]
+        keep = min(range(ncomp), key=lambda c: (-sizes[c], firsts[c]))
+        for c in range(ncomp):
+            if c == keep:
+                continue
+            p = firsts[c]
+            nb = p - 1 if p % W > 0 else p - W
+            if nb >= 0 and flat[nb] >= 0:
+                out[comp == c + 1] = flat[nb]
+    return out
+

@@ -132,3 +132,41 @@ def test_spatial_and_shape_single_segment():
     assert np.allclose(np.array(got[0]), np.array(want[0]), rtol=1e-9, atol=1e-12)
     line = np.arange(40, dtype=np.uint8).reshape(1, 40) * 5        # a 1 x N image
     assert np.array_equal(MPEG7Descriptors.cart2radial(line, one_dim=True), shape_ref.cart2radial(line))
+
+
+def test_connectivity_enforcement_matches_own_oracle():
+    """Additive step named by the task (no counterpart in scripts/slic.py, parity unpinned): the
+    device path (union-find components + per-component relabel) against the scipy restatement."""
+    torch = _torch()
+    from imgan import ops
+    from oracle.slic_ref import enforce_connectivity
+    rng = np.random.RandomState(12)
+    cases = []
+    a = np.repeat(np.repeat(rng.randint(0, 6, (9, 12)), 8, axis=0), 8, axis=1).astype(np.int32)
+    a[rng.rand(*a.shape) < 0.04] = 3                       # speckle: many one-pixel orphans
+    a[-1, :] = -1
+    a[:, -1] = -1                                          # the border SLIC leaves unlabelled
+    cases.append(a)
+    b = np.zeros((20, 30), np.int32)
+    b[:, 10:20] = 1
+    b[5:8, 12:15] = 0                                      # an island of 0 inside 1
+    b[0, 0] = 1                                            # orphan in the corner: no left / upper pixel
+    b[10, 0] = 1                                           # orphan in column 0: takes the label above
+    cases.append(b)
+    cases.append(np.full((7, 9), -1, np.int32))            # nothing labelled
+    cases.append(np.arange(6 * 5, dtype=np.int32).reshape(6, 5))   # every pixel its own label
+    for c in cases:
+        got = ops.enforce_connectivity(torch.from_numpy(c).cuda()).cpu().numpy()
+        assert np.array_equal(got, enforce_connectivity(c))
+    # on the class: labels after run() stay a valid superpixel map, orphans only shrink in number
+    from slic import SLICSuperPixel
+    from scipy import ndimage
+    sp = SLICSuperPixel(voronoi_image(120, 160, 10, seed=8, noise=25.0), 40, colour_weight=4, num_iter=5)
+    sp.run()
+    before = sp.get_clusters().copy()
+    after = sp.enforce_connectivity()
+
+    def ncomp(m):
+        return sum(ndimage.label(m == l, structure=np.ones((3, 3)))[1] for l in np.unique(m) if l >= 0)
+    assert np.array_equal(after, enforce_connectivity(before.astype(np.int32)).astype(np.float64))
+    assert ncomp(after) <= ncomp(before) and (after[before < 0] == -1).all()
