@@ -211,97 +211,107 @@ struct AssignParams {
     int* bbox;                // NULL, or [B][n][4] xmin, ymin, xmax, ymax of the new label map
 };
 
-// One wave per assignment tile: collects the centres whose window can reach the tile from the
-// cell lists, sorts them by centre index and writes a fixed-size record of 8-dword entries
+// Sixteen lanes per assignment tile (four tiles per wave): collects the centres whose window
+// can reach the tile from the cell lists, sorts them by centre index and writes a fixed-size
+// record of 8-dword entries
 //     {cx', cy', lab, idx, A, Bx, By, 0}       (cx', cy' relative to the tile origin)
 // with the per-candidate terms of the expanded integer key (see slic_assign_kernel):
 //     A = S^2 |c|^2 + cw^2 (cx'^2 + cy'^2),  Bx = 2 cw^2 cx',  By = 2 cw^2 cy'.
 // The assignment kernel reads the entries with scalar loads, so everything that is the same
 // for the whole wave (the entry itself, the row tests, the y part of the key) costs scalar
 // instructions only.
+// A tile sees about nine centres, so a whole wave per tile spent its time issuing instructions
+// for idle lanes (the kernel was bound by instruction issue, not by memory); a quarter wave per
+// tile issues a quarter of them.  Index arithmetic avoids integer division: the quotients are
+// below 2^24 and come from a float reciprocal with a one-step correction.
+constexpr int TG = 16;                 // lanes per tile
+constexpr int TILES_PER_WG = 256 / TG;
 __global__ __launch_bounds__(256) void slic_tiles_kernel(Ws w, AssignParams P) {
-    __shared__ int4 u_c[4][MAXC];
-    const int B = P.B, H = P.H, W = P.W, S = P.S, n = P.n;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ int4 u_c[TILES_PER_WG][MAXC];
+    const int H = P.H, W = P.W, S = P.S, n = P.n;
+    const int lane = threadIdx.x & 63, gl = lane & (TG - 1), gbase = lane & ~(TG - 1);
+    const int slot_wg = threadIdx.x / TG;
     const int ntiles = w.ntx * w.nty;
-    const long long t = (long long)blockIdx.x * 4 + wv;
-    if (t >= (long long)B * ntiles) return;              // wave uniform
+    const int b = (int)(blockIdx.z * 65535u + blockIdx.y);
+    if (b >= P.B) return;                                // workgroup uniform
+    const int ti = (int)blockIdx.x * TILES_PER_WG + slot_wg;
+    const bool live = ti < ntiles;
+    auto quot = [](int a, int d, float inv) {
+        int q = (int)((float)a * inv);
+        const int r = a - q * d;
+        return q + (r >= d) - (r < 0);
+    };
+    const float inv_s = 1.0f / (float)S, inv_ntx = 1.0f / (float)w.ntx;
+    const int ty = quot(live ? ti : 0, w.ntx, inv_ntx), tx = (live ? ti : 0) - ty * w.ntx;
+    const int x0 = tx * TW, y0 = ty * w.tile_h;
+    const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + w.tile_h - 1, H - 2);
+    // centres that can cover a pixel of the tile: cx in [x0-S+1, x1+S], cy likewise
+    const int cxl = quot(max(x0 - S + 1, 0), S, inv_s), cxh = min(quot(x1 + S, S, inv_s), w.ncx - 1);
+    const int cyl = quot(max(y0 - S + 1, 0), S, inv_s), cyh = min(quot(y1 + S, S, inv_s), w.ncy - 1);
+    const int4* scand = w.scand + (size_t)b * n;
+    const int* start = w.start + (size_t)b * (w.ncell + 1);
+    const int nrow = live ? cyh - cyl + 1 : 0;
+    const unsigned below = (1u << gl) - 1u;              // the lanes of the group before this one
+    int4* mine = u_c[slot_wg];
     int m = 0;
-    int b = 0, x0 = 0, y0 = 0;
-    {
-        b = (int)(t / ntiles);
-        const int ti = (int)(t - (long long)b * ntiles);
-        const int ty = ti / w.ntx, tx = ti - ty * w.ntx;
-        x0 = tx * TW;
-        y0 = ty * w.tile_h;
-        const int x1 = min(x0 + TW - 1, W - 2), y1 = min(y0 + w.tile_h - 1, H - 2);
-        // centres that can cover a pixel of the tile: cx in [x0-S+1, x1+S], cy likewise
-        const int cxl = max(x0 - S + 1, 0) / S, cxh = min((x1 + S) / S, w.ncx - 1);
-        const int cyl = max(y0 - S + 1, 0) / S, cyh = min((y1 + S) / S, w.ncy - 1);
-        const int4* scand = w.scand + (size_t)b * n;
-        const int* start = w.start + (size_t)b * (w.ncell + 1);
-        auto take = [&](int i, bool valid) {
+    // Cell rows in chunks of TG: lane r of the group fetches the bounds of row r0 + r, a prefix
+    // sum along the group places the rows' candidates side by side, and the lanes then take one
+    // candidate each (two memory round trips for a tile whose candidates fit the group).
+    for (int r0 = 0; __any(r0 < nrow); r0 += TG) {
+        int myb = 0, cnt = 0;
+        if (r0 + gl < nrow) {
+            myb = start[(cyl + r0 + gl) * w.ncx + cxl];
+            cnt = start[(cyl + r0 + gl) * w.ncx + cxh + 1] - myb;
+        }
+        int incl = cnt;                                  // inclusive prefix sum over the group
+#pragma unroll
+        for (int d = 1; d < TG; d <<= 1) {
+            const int up = __shfl(incl, lane - d);
+            if (gl >= d) incl += up;
+        }
+        const int total = __shfl(incl, gbase + TG - 1);
+        const int rows_here = min(max(nrow - r0, 0), TG);
+        for (int l0 = 0; __any(l0 < total); l0 += TG) {
+            const int l = l0 + gl;
+            const bool valid = l < total;
+            // the row of candidate l: the number of rows whose inclusive prefix is <= l
+            int r = 0;
+            for (int k = 0; __any(k < rows_here - 1); ++k) {
+                const int pk = __shfl(incl, gbase + k);
+                r += (k < rows_here - 1 && l >= pk) ? 1 : 0;
+            }
+            const int rb = __shfl(myb, gbase + r);
+            const int ri = __shfl(incl, gbase + r), rc = __shfl(cnt, gbase + r);
             bool hit = false;
             int4 q = make_int4(0, 0, 0, 0);
             if (valid) {
-                q = scand[i];
+                q = scand[rb + (l - (ri - rc))];
                 hit = q.x >= x0 - S + 1 && q.x <= x1 + S && q.y >= y0 - S + 1 && q.y <= y1 + S;
             }
-            const unsigned long long vote = __ballot(hit);
-            const int slot = m + __popcll(vote & ((1ull << lane) - 1ull));
-            if (hit && slot < MAXC) u_c[wv][slot] = q;
-            m += __popcll(vote);
-        };
-        const int nrow = cyh - cyl + 1;
-        if (nrow <= 8) {
-            // Two memory round trips for the whole tile: lane r fetches the bounds of cell row r,
-            // then the candidates of all rows are spread over the lanes (a loop over the rows
-            // would pay two dependent round trips per row).
-            int myb = 0, mye = 0;
-            if (lane < nrow) {
-                myb = start[(cyl + lane) * w.ncx + cxl];
-                mye = start[(cyl + lane) * w.ncx + cxh + 1];
-            }
-            int rb[8], rc[8], total = 0;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                rb[r] = __shfl(myb, r);
-                rc[r] = __shfl(mye, r) - rb[r];
-                total += rc[r];
-            }
-            for (int l0 = 0; l0 < total; l0 += 64) {
-                const int l = l0 + lane;
-                int i = 0, acc = 0;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    if (l >= acc && l < acc + rc[r]) i = rb[r] + (l - acc);
-                    acc += rc[r];
-                }
-                take(i, l < total);
-            }
-        } else {
-            for (int cyc = cyl; cyc <= cyh; ++cyc) {
-                const int beg = start[cyc * w.ncx + cxl], end = start[cyc * w.ncx + cxh + 1];
-                for (int i0 = beg; i0 < end; i0 += 64) take(i0 + lane, i0 + lane < end);
-            }
+            const unsigned vote = (unsigned)(__ballot(hit) >> gbase) & ((1u << TG) - 1u);
+            const int slot = m + __popc(vote & below);
+            if (hit && slot < MAXC) mine[slot] = q;
+            m += __popc(vote);
         }
     }
-    __builtin_amdgcn_wave_barrier();                     // u_c[wv] belongs to this wave alone
-    int8v* rec = w.tiles + (size_t)t * TILE_REC;
-    if (lane == 0) {
+    __builtin_amdgcn_wave_barrier();                     // a tile's list belongs to one wave
+    if (!live) return;
+    int8v* rec = w.tiles + ((size_t)b * ntiles + ti) * TILE_REC;
+    if (gl == 0) {
         int8v h = {m, x0, y0, 0, 0, 0, 0, 0};
         rec[0] = h;
     }
-    if (lane < m && m <= MAXC) {
-        const int4 me = u_c[wv][lane];
+    if (m > MAXC) return;
+    for (int e = gl; e < m; e += TG) {
+        const int4 me = mine[e];
         int rank = 0;
-        for (int j = 0; j < m; ++j) rank += (u_c[wv][j].w < me.w);
+        for (int j = 0; j < m; ++j) rank += (mine[j].w < me.w);
         const int cxr = me.x - x0, cyr = me.y - y0;
         const uint32_t cl = (uint32_t)me.z;
         const uint32_t cc = __builtin_amdgcn_udot4(cl, cl, 0u, false);
         const uint32_t A = P.S2 * cc + P.cw2 * (uint32_t)(cxr * cxr + cyr * cyr);
-        int8v e = {cxr, cyr, me.z, me.w, (int)A, 2 * (int)P.cw2 * cxr, 2 * (int)P.cw2 * cyr, 0};
-        rec[1 + rank] = e;
+        int8v e8 = {cxr, cyr, me.z, me.w, (int)A, 2 * (int)P.cw2 * cxr, 2 * (int)P.cw2 * cyr, 0};
+        rec[1 + rank] = e8;
     }
 }
 
@@ -946,9 +956,11 @@ extern "C" int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres
                        centres, w, B, H, W, S, n);
     hipLaunchKernelGGL(slic_scan_kernel, dim3(B), dim3(1024), 0, st, w);
     hipLaunchKernelGGL(slic_fill_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, w, B, n);
-    long long ntiles = (long long)B * L.ntx * L.nty;
-    hipLaunchKernelGGL(slic_tiles_kernel, dim3((unsigned)imgan::cdiv(ntiles, 4)), dim3(256), 0, st,
-                       w, P);
+    // grid: (tiles of one image / 16, images); the y extent of a grid stops at 65535
+    hipLaunchKernelGGL(slic_tiles_kernel,
+                       dim3((unsigned)imgan::cdiv((long long)L.ntx * L.nty, TILES_PER_WG),
+                            (unsigned)std::min(B, 65535), (unsigned)imgan::cdiv(B, 65535)),
+                       dim3(256), 0, st, w, P);
     return imgan::check_launch("slic_bin_centres");
 }
 
