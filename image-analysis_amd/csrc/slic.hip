@@ -202,6 +202,89 @@ __global__ void slic_fill_kernel(Ws w, int B, int n) {
     w.scand[(size_t)b * n + pos] = q;
 }
 
+// The three kernels above as one, for images whose cell grid fits LDS: one workgroup per image
+// counts, scans and places its centres without leaving the CU (no global atomics, no memset,
+// one launch instead of three plus a fill).
+constexpr int BIN_THREADS = 1024;
+constexpr int BIN_PER_THREAD = 4;                          // centres and cells per thread
+constexpr int BIN_MAX = BIN_THREADS * BIN_PER_THREAD;      // most centres and most cells per image
+__global__ __launch_bounds__(BIN_THREADS) void slic_bin_image_kernel(
+    const uint8_t* __restrict__ lab, const int32_t* __restrict__ centres, Ws w, int H, int W, int S,
+    int n) {
+    __shared__ int s_cnt[BIN_MAX];                         // counts, then exclusive starts
+    __shared__ int s_wave[BIN_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ncell = w.ncell;
+    for (int i = tid; i < ncell; i += BIN_THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    int4 q[BIN_PER_THREAD];
+    int rank[BIN_PER_THREAD];
+    const float inv_s = 1.0f / (float)S;
+    auto quot = [&](int a) {                               // a / S for 0 <= a < 2^24
+        int v = (int)((float)a * inv_s);
+        const int r = a - v * S;
+        return v + (r >= S) - (r < 0);
+    };
+#pragma unroll
+    for (int k = 0; k < BIN_PER_THREAD; ++k) {
+        const int c = tid + k * BIN_THREADS;
+        rank[k] = 0;
+        q[k] = make_int4(0, 0, 0, 0);
+        if (c < n) {
+            const int32_t* ce = centres + ((size_t)b * n + c) * 5;
+            const int cx = min(max(ce[3], 0), W - 1), cy = min(max(ce[4], 0), H - 1);
+            const uint8_t* px = lab + (((size_t)b * H + cy) * W + cx) * 3;
+            const int packed = px[0] | (px[1] << 8) | (px[2] << 16);
+            const int cell = quot(cy) * w.ncx + quot(cx);
+            q[k] = make_int4(cx, cy, packed, cell);
+            rank[k] = atomicAdd(&s_cnt[cell], 1);
+            unsigned long long* sm = w.sums + ((size_t)b * n + c) * NFIELD;
+#pragma unroll
+            for (int f = 0; f < NFIELD; ++f) sm[f] = 0ull;
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the counts: four consecutive cells per thread, a shuffle scan along the
+    // wave, the wave totals through LDS
+    int v[BIN_PER_THREAD], sum = 0;
+#pragma unroll
+    for (int k = 0; k < BIN_PER_THREAD; ++k) {
+        const int i = tid * BIN_PER_THREAD + k;
+        v[k] = i < ncell ? s_cnt[i] : 0;
+        sum += v[k];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int before = incl - sum;
+    for (int k = 0; k < wv; ++k) before += s_wave[k];
+    int* start = w.start + (size_t)b * (ncell + 1);
+#pragma unroll
+    for (int k = 0; k < BIN_PER_THREAD; ++k) {
+        const int i = tid * BIN_PER_THREAD + k;
+        if (i < ncell) {
+            s_cnt[i] = before;
+            start[i] = before;
+        }
+        before += v[k];
+    }
+    if (tid == 0) start[ncell] = n;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BIN_PER_THREAD; ++k) {
+        const int c = tid + k * BIN_THREADS;
+        if (c < n) {
+            const int pos = s_cnt[q[k].w] + rank[k];
+            w.scand[(size_t)b * n + pos] = make_int4(q[k].x, q[k].y, q[k].z, c);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ per-tile candidate lists
 struct AssignParams {
     int B, H, W, S, n, nsub, maxc;
@@ -949,13 +1032,19 @@ extern "C" int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres
     bool rel;
     AssignParams P = make_params(B, H, W, S, n, colour_weight, L, &mode, &rel);
     hipStream_t st = (hipStream_t)stream;
-    // count and fill are adjacent in the layout: one memset clears both
-    IMGAN_HIP(hipMemsetAsync(w.count, 0, L.off_start - L.off_count, st));
-    int total = B * n;
-    hipLaunchKernelGGL(slic_prepare_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, lab,
-                       centres, w, B, H, W, S, n);
-    hipLaunchKernelGGL(slic_scan_kernel, dim3(B), dim3(1024), 0, st, w);
-    hipLaunchKernelGGL(slic_fill_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, w, B, n);
+    if (n <= BIN_MAX && L.ncell <= BIN_MAX && H < (1 << 24) && W < (1 << 24)) {
+        hipLaunchKernelGGL(slic_bin_image_kernel, dim3(B), dim3(BIN_THREADS), 0, st, lab, centres, w,
+                           H, W, S, n);
+    } else {
+        // count and fill are adjacent in the layout: one memset clears both
+        IMGAN_HIP(hipMemsetAsync(w.count, 0, L.off_start - L.off_count, st));
+        int total = B * n;
+        hipLaunchKernelGGL(slic_prepare_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st,
+                           lab, centres, w, B, H, W, S, n);
+        hipLaunchKernelGGL(slic_scan_kernel, dim3(B), dim3(1024), 0, st, w);
+        hipLaunchKernelGGL(slic_fill_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, w, B,
+                           n);
+    }
     // grid: (tiles of one image / 16, images); the y extent of a grid stops at 65535
     hipLaunchKernelGGL(slic_tiles_kernel,
                        dim3((unsigned)imgan::cdiv((long long)L.ntx * L.nty, TILES_PER_WG),

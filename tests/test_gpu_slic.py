@@ -147,3 +147,23 @@ def test_slic_exact_ties_large_step(kind, K, cw):
     assert plan.S >= 48
     assert np.array_equal(labels.cpu().numpy()[0], want_labels)
     assert np.array_equal(centres.cpu().numpy()[0], want_centres)
+
+
+@pytest.mark.parametrize("H,W,K,B", [(512, 768, 6000, 1), (96, 160, 40, 3), (300, 200, 1500, 2)])
+def test_slic_binning_paths(H, W, K, B):
+    """The centres are binned by one workgroup per image while the cell grid fits LDS (4096 cells
+    and centres) and by the count / scan / fill kernels beyond: both against the C oracle
+    (bit-identical to the numpy oracle, tests/test_oracle_c.py), exactly."""
+    torch = _torch()
+    from imgan import ops
+    from oracle import c_oracle
+    from oracle.color import bgr2lab_u8
+    labs = np.stack([bgr2lab_u8(voronoi_image(H, W, max(K // 8, 6), seed=K + b)) for b in range(B)])
+    plan = ops.SlicPlan(B, H, W, K)
+    labels, centres = plan.run(torch.from_numpy(labs).cuda(), 15, 5)
+    if K == 6000:
+        assert plan.n > 4096                              # the three-kernel path
+    for b in range(B):
+        want_labels, want_centres = c_oracle.slic_run(labs[b], K, 15, 5)
+        assert np.array_equal(labels.cpu().numpy()[b], want_labels)
+        assert np.array_equal(centres.cpu().numpy()[b], want_centres)
