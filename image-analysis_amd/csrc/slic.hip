@@ -292,6 +292,7 @@ struct AssignParams {
     unsigned S2, cw2;         // integer key weights (modes 0, 1); cw2 = 0 in mode 2
     double Sd, cw;            // literal float64 evaluation (mode 2 and exact-key ties)
     int* bbox;                // NULL, or [B][n][4] xmin, ymin, xmax, ymax of the new label map
+    int first;                // first round: the incoming label map counts as all -1, unread
 };
 
 // Sixteen lanes per assignment tile (four tiles per wave): collects the centres whose window
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                 }
             }
             int lbl = bi;
-            if (bi >= 0)
+            if (bi >= 0 || P.first)
                 labels[li] = bi;
             else
                 lbl = labels[li];
@@ -845,7 +846,10 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                         atomicMax(q + 64, (uint32_t)yr);
                     }
                 } else {
-                    const int old = *lrow;            // not covered this round: keeps its label
+                    // not covered this round: keeps its label (-1 in the first round, which
+                    // writes it instead of reading it)
+                    if (P.first) *lrow = -1;
+                    const int old = P.first ? -1 : *lrow;
                     if (old >= 0) {
                         flush_pixel_global(sums, old, px[j], x, y);
                         if (bbox) bbox_point_global(bbox + ((size_t)b * n + old) * 4, x, y, x, y);
@@ -982,21 +986,41 @@ extern "C" size_t imgan_slic_workspace_bytes(int B, int H, int W, int S, int n) 
     return make_layout(B, H, W, S, n).total;
 }
 
+extern "C" int imgan_slic_seed_centres(const uint8_t* lab, int B, int H, int W, int S, int nx,
+                                       int ny, int32_t* centres, imgan_stream_t stream) {
+    IMGAN_REQUIRE(lab && centres, "imgan_slic_seed_centres: null pointer");
+    int n = nx * ny;
+    if (int rc = validate("imgan_slic_seed_centres", B, H, W, S, n)) return rc;
+    // the 3x3 search reads (x+2, y) and (x, y+2) around the last seed (slic.py:65-66)
+    IMGAN_REQUIRE(S + (nx - 1) * S + 2 <= W - 1 && S + (ny - 1) * S + 2 <= H - 1,
+                  "imgan_slic_init: seed grid too close to the image border (index out of bounds)");
+    int total = B * n;
+    hipLaunchKernelGGL(slic_init_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, lab, centres, B, H, W, S, nx, ny);
+    return imgan::check_launch("slic_init_kernel");
+}
+
 extern "C" int imgan_slic_init(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,
                                int32_t* centres, int32_t* labels, void* workspace,
                                imgan_stream_t stream) {
     IMGAN_REQUIRE(lab && centres && labels && workspace, "imgan_slic_init: null pointer");
-    int n = nx * ny;
-    if (int rc = validate("imgan_slic_init", B, H, W, S, n)) return rc;
-    // the 3x3 search reads (x+2, y) and (x, y+2) around the last seed (slic.py:65-66)
-    IMGAN_REQUIRE(S + (nx - 1) * S + 2 <= W - 1 && S + (ny - 1) * S + 2 <= H - 1,
-                  "imgan_slic_init: seed grid too close to the image border (index out of bounds)");
-    hipStream_t st = (hipStream_t)stream;
-    IMGAN_HIP(hipMemsetAsync(labels, 0xff, (size_t)B * H * W * 4, st));
-    int total = B * n;
-    hipLaunchKernelGGL(slic_init_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st, lab,
-                       centres, B, H, W, S, nx, ny);
-    return imgan::check_launch("slic_init_kernel");
+    if (int rc = imgan_slic_seed_centres(lab, B, H, W, S, nx, ny, centres, stream)) return rc;
+    IMGAN_HIP(hipMemsetAsync(labels, 0xff, (size_t)B * H * W * 4, (hipStream_t)stream));
+    return 0;
+}
+
+// The last row and the last column of a label map, which no round assigns (slic.py:95,97 stop
+// the windows at W - 1 and H - 1): -1 from the start.
+__global__ void slic_border_kernel(int32_t* __restrict__ labels, int B, int H, int W) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = H + W;
+    if (t >= (long long)B * per) return;
+    const int b = (int)(t / per), i = (int)(t - (long long)b * per);
+    int32_t* img = labels + (size_t)b * H * W;
+    if (i < W)
+        img[(size_t)(H - 1) * W + i] = -1;
+    else
+        img[(size_t)(i - W) * W + (W - 1)] = -1;
 }
 
 // Kernel parameters shared by the tile-record and the assignment kernels.
@@ -1016,6 +1040,7 @@ AssignParams make_params(int B, int H, int W, int S, int n, double colour_weight
     double m_est = (double)(TW + 2 * S) * (L.tile_h + 2 * S) / ((double)S * S);
     P.maxc = std::min(MAXC, std::max(16, ((int)(1.5 * m_est) + 4 + 7) / 8 * 8));
     P.bbox = nullptr;
+    P.first = 0;
     return P;
 }
 
@@ -1054,7 +1079,7 @@ extern "C" int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres
 }
 
 static int assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H, int W, int S, int n,
-                             double colour_weight, void* workspace, int32_t* bbox_out,
+                             double colour_weight, void* workspace, int32_t* bbox_out, bool first,
                              imgan_stream_t stream) {
     IMGAN_REQUIRE(lab && labels && workspace, "imgan_slic_assign_accumulate: null pointer");
     if (int rc = validate("imgan_slic_assign_accumulate", B, H, W, S, n)) return rc;
@@ -1072,6 +1097,14 @@ static int assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H, 
     IMGAN_REQUIRE((P.ntiles + 7) / 8 * 8 < 0x7fffffffLL, "imgan_slic_assign_accumulate: too many tiles");
     dim3 grid((unsigned)((P.ntiles + 7) / 8 * 8));
     hipStream_t st = (hipStream_t)stream;
+    if (first) {
+        // the incoming map counts as all -1 and is not read: the kernel writes every pixel it
+        // owns, the border nobody owns is written here
+        P.first = 1;
+        hipLaunchKernelGGL(slic_border_kernel,
+                           dim3((unsigned)imgan::cdiv((long long)B * (H + W), 256)), dim3(256), 0, st,
+                           labels, B, H, W);
+    }
     if (bbox_out) {
         P.bbox = bbox_out;
         lds_bytes += (size_t)P.maxc * 2 * 64 * sizeof(uint32_t);
@@ -1092,7 +1125,16 @@ static int assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H, 
 extern "C" int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H,
                                             int W, int S, int n, double colour_weight,
                                             void* workspace, imgan_stream_t stream) {
-    return assign_accumulate(lab, labels, B, H, W, S, n, colour_weight, workspace, nullptr, stream);
+    return assign_accumulate(lab, labels, B, H, W, S, n, colour_weight, workspace, nullptr, false,
+                             stream);
+}
+
+extern "C" int imgan_slic_assign_accumulate_first(const uint8_t* lab, int32_t* labels, int B, int H,
+                                                  int W, int S, int n, double colour_weight,
+                                                  void* workspace, int32_t* bbox_out,
+                                                  imgan_stream_t stream) {
+    return assign_accumulate(lab, labels, B, H, W, S, n, colour_weight, workspace, bbox_out, true,
+                             stream);
 }
 
 extern "C" int imgan_slic_assign_accumulate_bbox(const uint8_t* lab, int32_t* labels, int B, int H,
@@ -1100,7 +1142,8 @@ extern "C" int imgan_slic_assign_accumulate_bbox(const uint8_t* lab, int32_t* la
                                                  void* workspace, int32_t* bbox_out,
                                                  imgan_stream_t stream) {
     IMGAN_REQUIRE(bbox_out, "imgan_slic_assign_accumulate_bbox: null pointer");
-    return assign_accumulate(lab, labels, B, H, W, S, n, colour_weight, workspace, bbox_out, stream);
+    return assign_accumulate(lab, labels, B, H, W, S, n, colour_weight, workspace, bbox_out, false,
+                             stream);
 }
 
 extern "C" int imgan_slic_finalise_centres(int32_t* centres, int B, int H, int W, int S, int n,
@@ -1117,14 +1160,17 @@ extern "C" int imgan_slic_run(const uint8_t* lab, int B, int H, int W, int S, in
                               double colour_weight, int num_iter, int32_t* centres,
                               int32_t* labels, void* workspace, imgan_stream_t stream) {
     int n = nx * ny;
-    if (int rc = imgan_slic_init(lab, B, H, W, S, nx, ny, centres, labels, workspace, stream))
-        return rc;
+    if (num_iter <= 1)                                       // no round: the map stays all -1
+        return imgan_slic_init(lab, B, H, W, S, nx, ny, centres, labels, workspace, stream);
+    IMGAN_REQUIRE(labels && workspace, "imgan_slic_run: null pointer");
+    if (int rc = imgan_slic_seed_centres(lab, B, H, W, S, nx, ny, centres, stream)) return rc;
     for (int it = 1; it < num_iter; ++it) {                  // slic.py:84 -> num_iter - 1 rounds
         if (int rc = imgan_slic_bin_centres(lab, centres, B, H, W, S, n, colour_weight, workspace,
                                             stream))
             return rc;
-        if (int rc = imgan_slic_assign_accumulate(lab, labels, B, H, W, S, n, colour_weight,
-                                                  workspace, stream))
+        // the first round writes the whole map (no fill before it)
+        if (int rc = assign_accumulate(lab, labels, B, H, W, S, n, colour_weight, workspace,
+                                       nullptr, it == 1, stream))
             return rc;
         if (int rc = imgan_slic_finalise_centres(centres, B, H, W, S, n, workspace, stream))
             return rc;

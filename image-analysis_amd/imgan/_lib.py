@@ -33,6 +33,10 @@ SIGNATURES = {
                                              c_double, c_void_p, c_void_p]),
     "imgan_slic_assign_accumulate_bbox": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                                   c_int, c_double, c_void_p, c_void_p, c_void_p]),
+    "imgan_slic_seed_centres": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                        c_void_p]),
+    "imgan_slic_assign_accumulate_first": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                   c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "imgan_slic_finalise_centres": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                             c_void_p]),
     "imgan_slic_run": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_int,

@@ -118,24 +118,36 @@ class SlicPlan(object):
                                   _ptr(self.centres), _ptr(self.labels), _ptr(self.workspace),
                                   _stream()))
 
-    def round(self, lab, colour_weight, events=None, bbox=None):
+    def seed(self, lab):
+        """init() without the pass that fills the label map with -1: the map is undefined until
+        the first round, which must then be run as round(..., first=True)."""
+        lab = self._check(lab)
+        check(lib.imgan_slic_seed_centres(_ptr(lab), self.B, self.H, self.W, self.S, self.nx,
+                                          self.ny, _ptr(self.centres), _stream()))
+
+    def round(self, lab, colour_weight, events=None, bbox=None, first=False):
         """One iteration of slic.py:84-126.  `events`: optional (start, end) torch events
         recorded around the assignment kernel on the current stream (bench.py roofline).
         `bbox`: optional device buffer of at least B*n*16 bytes that receives the bounding box
-        int32 [B,n,4] of every label of the updated map (for DcdPlan.kmeans(boxed=True))."""
+        int32 [B,n,4] of every label of the updated map (for DcdPlan.kmeans(boxed=True)).
+        `first`: the round after seed(): the label map counts as all -1 and is written in full."""
         lab = self._check(lab)
         a = (self.B, self.H, self.W, self.S, self.n)
         check(lib.imgan_slic_bin_centres(_ptr(lab), _ptr(self.centres), *a, float(colour_weight),
                                          _ptr(self.workspace), _stream()))
         if events:
             events[0].record()
-        if bbox is None:
+        if bbox is not None and bbox.numel() * bbox.element_size() < self.B * self.n * 16:
+            raise ValueError("bbox buffer too small")
+        if first:
+            check(lib.imgan_slic_assign_accumulate_first(
+                _ptr(lab), _ptr(self.labels), *a, float(colour_weight), _ptr(self.workspace),
+                _ptr(bbox) if bbox is not None else None, _stream()))
+        elif bbox is None:
             check(lib.imgan_slic_assign_accumulate(_ptr(lab), _ptr(self.labels), *a,
                                                    float(colour_weight), _ptr(self.workspace),
                                                    _stream()))
         else:
-            if bbox.numel() * bbox.element_size() < self.B * self.n * 16:
-                raise ValueError("bbox buffer too small")
             check(lib.imgan_slic_assign_accumulate_bbox(_ptr(lab), _ptr(self.labels), *a,
                                                         float(colour_weight), _ptr(self.workspace),
                                                         _ptr(bbox), _stream()))

@@ -45,16 +45,20 @@ class FullPipeline(object):
 
     def run_slic(self, bgr, timed=False):
         self._timed("bgr2lab", timed, lambda: ops.bgr2lab(bgr, out=self.lab))
-        self.slic.init(self.lab)
+        # with at least one round the first one writes the whole label map: no fill before it
+        if self.num_iter > 1:
+            self.slic.seed(self.lab)
+        else:
+            self.slic.init(self.lab)
         for it in range(1, self.num_iter):
             # the last round also leaves the bounding boxes of the superpixels for run_dcd
             box = self.dcd.bbox if (it == self.num_iter - 1 and self.dcd is not None) else None
             if timed:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                self.slic.round(self.lab, self.cw, events=ev, bbox=box)
+                self.slic.round(self.lab, self.cw, events=ev, bbox=box, first=(it == 1))
                 self.stage_events.setdefault("slic_assign", []).append(ev)
             else:
-                self.slic.round(self.lab, self.cw, bbox=box)
+                self.slic.round(self.lab, self.cw, bbox=box, first=(it == 1))
         self.boxed = self.dcd is not None and self.num_iter > 1
         return self.slic.labels
 
@@ -121,14 +125,17 @@ class RagPipeline(object):
         import time
         self._timed("median7", timed, lambda: ops.median7(bgr, out=self.blur))
         self._timed("bgr2lab", timed, lambda: ops.bgr2lab(self.blur, out=self.lab))
-        self.slic.init(self.lab)
-        for _ in range(1, self.num_iter):
+        if self.num_iter > 1:
+            self.slic.seed(self.lab)
+        else:
+            self.slic.init(self.lab)
+        for it in range(1, self.num_iter):
             if timed:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                self.slic.round(self.lab, self.cw, events=ev)
+                self.slic.round(self.lab, self.cw, events=ev, first=(it == 1))
                 self.stage_events.setdefault("slic_assign", []).append(ev)
             else:
-                self.slic.round(self.lab, self.cw)
+                self.slic.round(self.lab, self.cw, first=(it == 1))
         labels = self.slic.labels
         t0 = time.perf_counter()
         sums, edges = ops.rag_accumulate(self.lab, labels, self.K)      # synchronises (edge lists)

@@ -64,6 +64,12 @@ size_t imgan_slic_workspace_bytes(int B, int H, int W, int S, int n);
 int imgan_slic_init(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,
                     int32_t* centres, int32_t* labels, void* workspace, imgan_stream_t stream);
 
+/* The seeding half of imgan_slic_init alone (slic.py:35-76): centres only, no label map.  For
+ * callers that run the first round with imgan_slic_assign_accumulate_first and so never need
+ * the map filled with -1 (slic.py:81) in a pass of its own. */
+int imgan_slic_seed_centres(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,
+                            int32_t* centres, imgan_stream_t stream);
+
 /* Candidate lookup for the next assignment: re-bins the centres into S x S cells and writes,
  * for every 64-pixel-wide tile, the sorted list of centres whose window (slic.py:94-100) can
  * reach it, with the per-centre terms of the distance of slic.py:101-109 (hence the colour
@@ -84,6 +90,14 @@ int imgan_slic_assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int
 int imgan_slic_assign_accumulate_bbox(const uint8_t* lab, int32_t* labels, int B, int H, int W,
                                       int S, int n, double colour_weight, void* workspace,
                                       int32_t* bbox_out, imgan_stream_t stream);
+
+/* The first round after imgan_slic_seed_centres: as imgan_slic_assign_accumulate (with
+ * bbox_out, which may be NULL, as imgan_slic_assign_accumulate_bbox) on a label map that counts
+ * as all -1 (slic.py:81) whatever it holds: the map is written in full, not read, which saves
+ * the pass that would fill it. */
+int imgan_slic_assign_accumulate_first(const uint8_t* lab, int32_t* labels, int B, int H, int W,
+                                       int S, int n, double colour_weight, void* workspace,
+                                       int32_t* bbox_out, imgan_stream_t stream);
 
 /* slic.py:124-126: centre = floor(sum / count), empty cluster -> 0. */
 int imgan_slic_finalise_centres(int32_t* centres, int B, int H, int W, int S, int n,

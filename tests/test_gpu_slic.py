@@ -167,3 +167,46 @@ def test_slic_binning_paths(H, W, K, B):
         want_labels, want_centres = c_oracle.slic_run(labs[b], K, 15, 5)
         assert np.array_equal(labels.cpu().numpy()[b], want_labels)
         assert np.array_equal(centres.cpu().numpy()[b], want_centres)
+
+
+@pytest.mark.parametrize("H,W,K,cw", [(101, 157, 60, 15), (213, 320, 200, 15), (64, 64, 256, 10),
+                                       (200, 260, 16, 15), (96, 128, 12, 0.5)])
+def test_slic_first_round_writes_the_whole_map(H, W, K, cw):
+    """seed() + round(first=True) never fills the label map with -1 (slic.py:81): the first round
+    must write every pixel itself, the uncovered ones and the border included.  The map is
+    poisoned beforehand; the result must equal the init() path and the oracle, exactly."""
+    torch = _torch()
+    from imgan import ops
+    from oracle import c_oracle
+    from oracle.color import bgr2lab_u8
+    rng = np.random.RandomState(H + K)
+    # a noisy image makes the centres drift, which leaves pixels out of every window
+    img = (voronoi_image(H, W, max(K // 4, 5), seed=H) // 2 + rng.randint(0, 128, (H, W, 3))).astype(np.uint8)
+    lab = bgr2lab_u8(img)
+    dev = torch.from_numpy(lab[None]).cuda()
+    for rounds in (1, 4):
+        ref = ops.SlicPlan(1, H, W, K)
+        ref.init(dev)
+        for _ in range(rounds):
+            ref.round(dev, cw)
+        plan = ops.SlicPlan(1, H, W, K)
+        plan.labels.fill_(0x5a5a5a5a)
+        plan.seed(dev)
+        for it in range(rounds):
+            plan.round(dev, cw, first=(it == 0))
+        assert torch.equal(plan.labels, ref.labels)
+        assert torch.equal(plan.centres, ref.centres)
+        fused = ops.SlicPlan(1, H, W, K)
+        fused.labels.fill_(0x5a5a5a5a)
+        fused.run(dev, cw, rounds + 1)
+        assert torch.equal(fused.labels, ref.labels)
+        got = ref.labels.cpu().numpy()[0]
+        assert (got[-1] == -1).all() and (got[:, -1] == -1).all()
+    if float(cw) == int(cw):
+        want_labels, want_centres = c_oracle.slic_run(lab, K, cw, 5)
+        assert np.array_equal(got, want_labels)
+    # no round at all: the map is all -1
+    none = ops.SlicPlan(1, H, W, K)
+    none.labels.fill_(7)
+    none.run(dev, cw, 1)
+    assert int((none.labels != -1).sum()) == 0
