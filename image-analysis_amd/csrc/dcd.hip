@@ -302,26 +302,30 @@ __global__ void dcd_init_fetch_kernel(const uint8_t* __restrict__ lab, long long
 __global__ void dcd_features_kernel(const unsigned long long* __restrict__ stats,
                                     const float* __restrict__ centres, int nsegs, int k,
                                     float* __restrict__ out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nsegs) return;
-    const unsigned long long* st = stats + (size_t)t * k * 8;
+    // one thread per (segment, colour): the rows of stats and out are read and written whole
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)nsegs * k) return;
+    const long long seg = t / k;
+    const unsigned long long* st = stats + (size_t)seg * k * 8;
     unsigned long long total = 0;
     for (int j = 0; j < k; ++j) total += st[8 * j];
-    for (int j = 0; j < k; ++j) {
-        const unsigned long long* a = st + 8 * j;
-        float* o = out + ((size_t)t * k + j) * 8;
-        const float* c = centres + ((size_t)t * k + j) * 3;
-        o[0] = c[0];
-        o[1] = c[1];
-        o[2] = c[2];
-        double n = (double)a[0];
-        for (int ch = 0; ch < 3; ++ch) {
-            double sx = (double)a[1 + ch], sxx = (double)a[4 + ch];
-            o[3 + ch] = a[0] ? (float)((n * sxx - sx * sx) / (n * n)) : __builtin_nanf("");
-        }
-        o[6] = total ? (float)(n / (double)total) : 0.f;
-        o[7] = a[0] ? (float)((double)a[7] / n) : 0.f;
+    const unsigned long long* a = stats + (size_t)t * 8;
+    float* o = out + (size_t)t * 8;
+    const float* c = centres + (size_t)t * 3;
+    float r[8];
+    r[0] = c[0];
+    r[1] = c[1];
+    r[2] = c[2];
+    const unsigned long long cnt = a[0];
+    const double n = (double)cnt;
+    for (int ch = 0; ch < 3; ++ch) {
+        double sx = (double)a[1 + ch], sxx = (double)a[4 + ch];
+        r[3 + ch] = cnt ? (float)((n * sxx - sx * sx) / (n * n)) : __builtin_nanf("");
     }
+    r[6] = total ? (float)(n / (double)total) : 0.f;
+    r[7] = cnt ? (float)((double)a[7] / n) : 0.f;
+    reinterpret_cast<float4*>(o)[0] = make_float4(r[0], r[1], r[2], r[3]);
+    reinterpret_cast<float4*>(o)[1] = make_float4(r[4], r[5], r[6], r[7]);
 }
 
 }  // namespace
@@ -428,8 +432,10 @@ extern "C" int imgan_dcd_features(const uint64_t* stats, const float* centres, i
                                   int k, float* features, imgan_stream_t stream) {
     IMGAN_REQUIRE(stats && centres && features, "imgan_dcd_features: null pointer");
     IMGAN_REQUIRE(B >= 1 && nseg >= 1 && k >= 1 && k <= KMAX, "imgan_dcd_features: bad shape");
+    IMGAN_REQUIRE(((uintptr_t)features & 15) == 0, "imgan_dcd_features: features must be 16-byte aligned");
     int nsegs = B * nseg;
-    hipLaunchKernelGGL(dcd_features_kernel, dim3(imgan::cdiv(nsegs, 128)), dim3(128), 0,
+    hipLaunchKernelGGL(dcd_features_kernel, dim3((unsigned)imgan::cdiv((long long)nsegs * k, 256)),
+                       dim3(256), 0,
                        (hipStream_t)stream, (const unsigned long long*)stats, centres, nsegs, k,
                        features);
     return imgan::check_launch("dcd_features_kernel");

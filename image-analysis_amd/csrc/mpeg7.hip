@@ -160,15 +160,20 @@ __device__ int quant_ac(int i) {
     return j + 128;
 }
 
-// one thread per (image, channel): averages -> YCbCr -> 8x8 DCT -> zig-zag -> quantise
-__global__ void cld_finalise_kernel(const unsigned long long* __restrict__ sums, int B,
-                                    int32_t* __restrict__ out, DctTable T) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per (image, channel), one lane per grid cell / coefficient: averages -> YCbCr ->
+// 8x8 DCT -> zig-zag -> quantise.  Every sum runs over k in the order of the serial statement.
+__global__ __launch_bounds__(64) void cld_finalise_kernel(const unsigned long long* __restrict__ sums,
+                                                          int B, int32_t* __restrict__ out,
+                                                          DctTable T) {
+    __shared__ double s_t[64], blk[64], tmp[64];
+    __shared__ int coef[64];
+    const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= B * 3) return;
-    int b = t / 3, ch = t - b * 3;
+    const int b = t / 3, ch = t - b * 3;
     const unsigned long long* S = sums + (size_t)b * 64 * 4;
-    double blk[64], tmp[64];
-    for (int k = 0; k < 64; ++k) {
+    s_t[lane] = T.c[lane];
+    {
+        const int k = lane;
         unsigned long long n = S[4 * k + 3];
         double Bc = 0.0, Gc = 0.0, Rc = 0.0;
         if (n) {
@@ -183,24 +188,26 @@ __global__ void cld_finalise_kernel(const unsigned long long* __restrict__ sums,
         else v = (double)(int)(224.0 * 0.713 * (Rc / 256.0 * 1.0 - yy) + 128.5);
         blk[k] = v;
     }
-    for (int i = 0; i < 8; ++i)
-        for (int j = 0; j < 8; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < 8; ++k) s += T.c[j * 8 + k] * blk[8 * i + k];
-            tmp[8 * i + j] = s;
-        }
-    int coef[64];
-    for (int j = 0; j < 8; ++j)
-        for (int i = 0; i < 8; ++i) {
-            double s = 0.0;
-            for (int k = 0; k < 8; ++k) s += T.c[i * 8 + k] * tmp[8 * k + j];
-            coef[8 * i + j] = (int)floor(s + 0.499999);
-        }
+    __syncthreads();
+    const int i = lane >> 3, j = lane & 7;
+    {
+        double s = 0.0;
+        for (int k = 0; k < 8; ++k) s += s_t[j * 8 + k] * blk[8 * i + k];
+        tmp[8 * i + j] = s;
+    }
+    __syncthreads();
+    {
+        double s = 0.0;
+        for (int k = 0; k < 8; ++k) s += s_t[i * 8 + k] * tmp[8 * k + j];
+        coef[8 * i + j] = (int)floor(s + 0.499999);
+    }
+    __syncthreads();
     int32_t* o = out + ((size_t)b * 3 + ch) * 64;
-    o[0] = ch == 0 ? (quant_ydc(coef[0] / 8) >> 1) : quant_cdc(coef[0] / 8);
-    for (int i = 1; i < 64; ++i) {
-        int v = coef[kZigzag[i]];
-        o[i] = ch == 0 ? (quant_ac(v / 2) >> 3) : (quant_ac(v) >> 3);
+    if (lane == 0) {
+        o[0] = ch == 0 ? (quant_ydc(coef[0] / 8) >> 1) : quant_cdc(coef[0] / 8);
+    } else {
+        const int v = coef[kZigzag[lane]];
+        o[lane] = ch == 0 ? (quant_ac(v / 2) >> 3) : (quant_ac(v) >> 3);
     }
 }
 
@@ -444,7 +451,7 @@ extern "C" int imgan_cld(const uint8_t* bgr, int B, int H, int W, int32_t* cld_o
         double s = i == 0 ? sqrt(0.125) : 0.5;
         for (int j = 0; j < 8; ++j) T.c[i * 8 + j] = s * cos((M_PI / 8.0) * i * (j + 0.5));
     }
-    hipLaunchKernelGGL(cld_finalise_kernel, dim3(imgan::cdiv(B * 3, 64)), dim3(64), 0, st,
+    hipLaunchKernelGGL(cld_finalise_kernel, dim3(B * 3), dim3(64), 0, st,
                        (const unsigned long long*)scratch, B, cld_out, T);
     return imgan::check_launch("imgan_cld");
 }

@@ -214,7 +214,7 @@ int imgan_dcd_segments_boxed(const uint8_t* lab, const int32_t* labels, int B, i
                              int32_t* n_big_out, int max_rounds, imgan_stream_t stream);
 
 /* mpeg7Descriptors.py:114-129 from the integer statistics: features float32 [B][nseg][k][8] =
- * mean(3), population variance(3), percentage, spatial coherence. */
+ * mean(3), population variance(3), percentage, spatial coherence (16-byte aligned). */
 int imgan_dcd_features(const uint64_t* stats, const float* centres, int B, int nseg, int k,
                        float* features, imgan_stream_t stream);
 
