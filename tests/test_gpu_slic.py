@@ -149,7 +149,8 @@ def test_slic_exact_ties_large_step(kind, K, cw):
     assert np.array_equal(centres.cpu().numpy()[0], want_centres)
 
 
-@pytest.mark.parametrize("H,W,K,B", [(512, 768, 6000, 1), (96, 160, 40, 3), (300, 200, 1500, 2)])
+@pytest.mark.parametrize("H,W,K,B", [(512, 768, 6000, 1), (96, 160, 40, 3), (300, 200, 1500, 2),
+                                      (65, 65, 1056, 1), (100, 130, 1400, 2)])    # the last two: S = 2 and 3
 def test_slic_binning_paths(H, W, K, B):
     """The centres are binned by one workgroup per image while the cell grid fits LDS (4096 cells
     and centres) and by the count / scan / fill kernels beyond: both against the C oracle
