@@ -1052,6 +1052,10 @@ extern "C" int imgan_slic_bin_centres(const uint8_t* lab, const int32_t* centres
     IMGAN_REQUIRE(colour_weight > 0.0 && isfinite(colour_weight),
                   "imgan_slic_bin_centres: colour_weight must be positive");
     Layout L = make_layout(B, H, W, S, n);
+    // the tile kernel takes its quotients from float reciprocals, exact below 2^24
+    IMGAN_REQUIRE((long long)L.ntx * L.nty < (1 << 24) && (long long)W + S < (1 << 24) &&
+                      (long long)H + S < (1 << 24),
+                  "imgan_slic_bin_centres: image too large");
     Ws w = bind(workspace, L);
     int mode;
     bool rel;
