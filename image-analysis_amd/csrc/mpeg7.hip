@@ -300,6 +300,14 @@ struct HmmdTab {
     int nhue[5], nsum[5], off[5];
 };
 
+// a / d for 0 <= a < 2^24, 0 < d, a / d < 2^20: float reciprocal and one correction step
+// (exact, a quarter of the instructions of an integer division)
+__device__ __forceinline__ int small_quot(int a, int d) {
+    int q = (int)((float)a * __frcp_rn((float)d));
+    const int r = a - q * d;
+    return q + (r >= d) - (r < 0);
+}
+
 __device__ __forceinline__ int hmmd_cell(int b, int g, int r, const HmmdTab& T) {
     int mx = max(max(r, g), b), mn = min(min(r, g), b);
     int d = mx - mn, s2 = mx + mn;
@@ -310,14 +318,14 @@ __device__ __forceinline__ int hmmd_cell(int b, int g, int r, const HmmdTab& T) 
         else if (g == mx) num = 120 * d + 60 * (b - r);
         else num = 240 * d + 60 * (r - g);
         if (num < 0) num += 360 * d;
-        hue = (2 * num + d) / (2 * d);
+        hue = small_quot(2 * num + d, 2 * d);
         if (hue >= 360) hue -= 360;
     }
     int sub = 0;
     for (int i = 1; i < T.nsub; ++i) sub += (d >= T.thr[i]);
     int lo = T.thr[sub];
     int ihue = hue * T.nhue[sub] / 360;
-    int isum = (s2 - lo) * T.nsum[sub] / (2 * (256 - lo));
+    int isum = small_quot((s2 - lo) * T.nsum[sub], 2 * (256 - lo));
     return T.off[sub] + ihue * T.nsum[sub] + isum;
 }
 
@@ -337,39 +345,33 @@ constexpr int CS_W = 32, CS_H = 8, CS_PW = CS_W + 7, CS_PH = CS_H + 7;
 __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ img, int H, int W,
                                                   int K, int nwx, int nwy, int nbins,
                                                   int32_t* __restrict__ out, HmmdTab T) {
-    __shared__ uint8_t cell[CS_PH * CS_PW];
     __shared__ uint32_t runs[CS_PH * 8 * CS_W];     // [patch row][mask word][column]
     __shared__ uint32_t hist[256];
     const int b = blockIdx.z;
     const int u0 = blockIdx.x * CS_W, v0 = blockIdx.y * CS_H;
     const uint8_t* im = img + (size_t)b * H * W * 3;
     for (int i = threadIdx.x; i < 256; i += 256) hist[i] = 0;
-    for (int i = threadIdx.x; i < CS_PH * CS_PW; i += 256) {
-        int pv = i / CS_PW, pu = i - pv * CS_PW;
-        int u = u0 + pu, v = v0 + pv;
-        uint8_t c = 0;
-        if (u < nwx + 7 && v < nwy + 7) {
-            const uint8_t* q = im + ((size_t)(v * K) * W + (size_t)u * K) * 3;
-            c = (uint8_t)hmmd_cell(q[0], q[1], q[2], T);
-        }
-        cell[i] = c;
-    }
+    for (int i = threadIdx.x; i < CS_PH * 8 * CS_W / 4; i += 256)
+        reinterpret_cast<uint4*>(runs)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     // The 8 x 8 structuring element is separable for "which colours occur": first the set of
     // colours (a 256-bit mask, 8 words) of every horizontal run of 8 cells, once per patch row
-    // and column, then each window ORs the 8 runs below its origin.
-    for (int i = threadIdx.x; i < CS_PH * CS_W; i += 256) {
-        const int pv = i >> 5, pu = i & 31;
-        uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int du = 0; du < 8; ++du) {
-            const uint32_t c = cell[pv * CS_PW + pu + du];
-            const uint32_t bit = 1u << (c & 31u), wsel = c >> 5;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) r[w] |= (wsel == (uint32_t)w) ? bit : 0u;
+    // and column, then each window ORs the 8 runs below its origin.  A cell sets its bit in the
+    // eight runs that contain it with LDS atomics (building a run in registers from its eight
+    // cells cost 24 instructions per cell, and this kernel is bound by instruction issue).
+    for (int i = threadIdx.x; i < CS_PH * CS_PW; i += 256) {
+        int pv = i / CS_PW, pu = i - pv * CS_PW;
+        int u = u0 + pu, v = v0 + pv;
+        uint32_t c = 0;
+        if (u < nwx + 7 && v < nwy + 7) {
+            const uint8_t* q = im + ((size_t)(v * K) * W + (size_t)u * K) * 3;
+            c = (uint32_t)hmmd_cell(q[0], q[1], q[2], T);
         }
+        const uint32_t bit = 1u << (c & 31u);
+        uint32_t* row = runs + (pv * 8 + (int)(c >> 5)) * CS_W;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) runs[(pv * 8 + w) * CS_W + pu] = r[w];   // lanes along pu
+        for (int du = 0; du < 8; ++du)
+            if ((unsigned)(pu - du) < (unsigned)CS_W) atomicOr(&row[pu - du], bit);
     }
     __syncthreads();
     const int tu = threadIdx.x & 31, tv = threadIdx.x >> 5;
