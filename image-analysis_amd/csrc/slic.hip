@@ -498,6 +498,15 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 
 // 7 waves per SIMD: what the LDS of the common configurations allows (one workgroup = one wave
 // per SIMD); without the hint the compiler settles on 77 registers, one wave short of that
+#ifdef IMGAN_ASSIGN_COUNTS
+// which epilogue the bands of the assignment kernel take (tools/assign_counts.py; never built
+// into the product): 0 fast, 1 rows not full, 2 more centres than LDS slots, 3 uncovered pixel,
+// 4 bands with a tie replay
+__device__ unsigned long long assign_counts[8];
+#define ASSIGN_COUNT(i) do { if (lane == 0) atomicAdd(&assign_counts[i], 1ull); } while (0)
+#else
+#define ASSIGN_COUNT(i) do { } while (0)
+#endif
 #ifndef IMGAN_ASSIGN_WAVES
 #define IMGAN_ASSIGN_WAVES __attribute__((amdgpu_waves_per_eu(7, 7)))
 #endif
@@ -737,6 +746,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
 #pragma unroll
             for (int j = 0; j < R; ++j) any_tie |= __builtin_amdgcn_ballot_w64(best2[j] == best[j]);
             if (any_tie != 0ull) {                       // wave uniform, rarely taken
+                ASSIGN_COUNT(4);
 #pragma unroll
                 for (int j = 0; j < R; ++j)
                     tied |= (best2[j] == best[j] && slot[j] >= 0) ? (1u << j) : 0u;
@@ -798,6 +808,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
         for (int j = 1; j < R; ++j) lowest = min(lowest, slot[j]);
         const bool rows_full = y0 + wy0 + R <= H - 1;
         if (rows_full && m <= maxc && __builtin_amdgcn_ballot_w64(colok && lowest < 0) == 0ull) {
+            ASSIGN_COUNT(0);
             // the common case, free of per-row branches: every pixel of the wave has a centre
             if (colok) {
                 int lbl[R];
@@ -823,6 +834,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                 }
             }
         } else {
+            ASSIGN_COUNT(!rows_full ? 1 : m > maxc ? 2 : 3);
             int32_t* lrow = rowp + lane;
 #pragma unroll
             for (int j = 0; j < R; ++j, lrow += W) {
@@ -1149,6 +1161,18 @@ extern "C" int imgan_slic_assign_accumulate_bbox(const uint8_t* lab, int32_t* la
     return assign_accumulate(lab, labels, B, H, W, S, n, colour_weight, workspace, bbox_out, false,
                              stream);
 }
+
+#ifdef IMGAN_ASSIGN_COUNTS
+extern "C" int imgan_debug_assign_counts(unsigned long long* out8, int reset) {
+    IMGAN_HIP(hipDeviceSynchronize());
+    IMGAN_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(assign_counts), 64));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        IMGAN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(assign_counts), z, 64));
+    }
+    return 0;
+}
+#endif
 
 extern "C" int imgan_slic_finalise_centres(int32_t* centres, int B, int H, int W, int S, int n,
                                            void* workspace, imgan_stream_t stream) {
