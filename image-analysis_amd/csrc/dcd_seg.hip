@@ -236,7 +236,10 @@ __device__ __forceinline__ void segment_body(
 #endif
     if (!FIRST && seg[gs].handled) return;
     const int* bb = bbox + gs * 4;
-    const int xmin = bb[0], ymin = bb[1], xmax = bb[2], ymax = bb[3];
+    // clamped into the image: the boxes may come from the caller (imgan_dcd_segments_boxed), and a
+    // box outside the image must not turn into a read outside the buffers
+    const int xmin = max(bb[0], 0), ymin = max(bb[1], 0);
+    const int xmax = min(bb[2], W - 1), ymax = min(bb[3], H - 1);
     SegState st;
     st.old_sum = 0.0;
     st.done = 1;
@@ -244,7 +247,7 @@ __device__ __forceinline__ void segment_body(
     st.handled = 1;
     st.pad = 0;
     unsigned long long* out = stats + gs * k * 8;
-    if (xmax < 0) {                                     // segment id without pixels
+    if (xmax < xmin || ymax < ymin) {                   // segment id without pixels
         if (tid == 0) seg[gs] = st;
         for (int i = tid; i < k * 8; i += THREADS) out[i] = 0ull;
         return;

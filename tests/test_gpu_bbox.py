@@ -92,6 +92,30 @@ def test_dominant_colours_with_given_boxes_equal_the_plain_call():
     assert torch.equal(pipe.features.view(torch.int32), feats.view(torch.int32))
 
 
+def test_boxes_beyond_the_image_are_clamped():
+    """Boxes handed to imgan_dcd_segments_boxed come from the caller: sides pushed past the image
+    edge must be clamped by the kernel (same result as the exact boxes), not read out of bounds."""
+    import torch
+    from imgan.pipeline import FullPipeline
+    B, H, W, K = 2, 216, 384, 60
+    img = np.stack([voronoi_image(H, W, 20, seed=80 + b) for b in range(B)])
+    bgr = torch.from_numpy(img).cuda()
+    pipe = FullPipeline(B, H, W, K)
+    pipe.run_slic(bgr)
+    pipe.run_dcd()
+    feats, assign, stats = pipe.features.clone(), pipe.dcd.assign.clone(), pipe.dcd.stats.clone()
+    box = pipe.dcd.bbox[:B * pipe.n * 16].view(torch.int32).view(B, pipe.n, 4)
+    live = box[..., 2] >= 0
+    box[..., 0] = torch.where(live & (box[..., 0] == 0), torch.full_like(box[..., 0], -3), box[..., 0])
+    box[..., 1] = torch.where(live & (box[..., 1] == 0), torch.full_like(box[..., 1], -5), box[..., 1])
+    box[..., 2] = torch.where(live & (box[..., 2] == W - 2), torch.full_like(box[..., 2], W + 7), box[..., 2])
+    box[..., 3] = torch.where(live & (box[..., 3] == H - 2), torch.full_like(box[..., 3], H + 2), box[..., 3])
+    assert int((box[..., 0] < 0).sum()) > 0 and int((box[..., 3] >= H).sum()) > 0
+    pipe.run_dcd()
+    assert torch.equal(pipe.dcd.stats, stats) and torch.equal(pipe.dcd.assign, assign)
+    assert torch.equal(pipe.features.view(torch.int32), feats.view(torch.int32))
+
+
 def test_crowded_tile_takes_the_fast_loop_with_global_overflow_slots():
     """More centres reach one tile than its LDS accumulators were sized for (but no more than a
     tile record holds): the pixels won by the slots beyond go to global memory one by one.
