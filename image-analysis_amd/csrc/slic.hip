@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                 labels[li] = bi;
             else
                 lbl = labels[li];
-            if (lbl >= 0) {
+            if ((unsigned)lbl < (unsigned)n) {            // a kept label comes from the caller's map
                 flush_pixel_global(sums, lbl, px, x, y);
                 if (bbox) bbox_point_global(bbox + ((size_t)b * n + lbl) * 4, x, y, x, y);
             }
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                     // writes it instead of reading it)
                     if (P.first) *lrow = -1;
                     const int old = P.first ? -1 : *lrow;
-                    if (old >= 0) {
+                    if ((unsigned)old < (unsigned)n) {    // it comes from the caller's map
                         flush_pixel_global(sums, old, px[j], x, y);
                         if (bbox) bbox_point_global(bbox + ((size_t)b * n + old) * 4, x, y, x, y);
                     }
