@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libimgan_hip.so")
+# IMGAN_LIB: an experiment build of the same library (tools/exp_run.sh); never a fallback
+LIB_PATH = os.environ.get("IMGAN_LIB") or os.path.join(_HERE, "libimgan_hip.so")
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int

@@ -13,8 +13,13 @@ import numpy as np
 import torch
 
 from imgan import ops
-from metric_methods import euclidean_dist
 from slic import SLICSuperPixel
+
+
+def euclidean_dist(a, b):
+    # the one helper find_edges takes from scripts/metric_methods.py (:5-6); the rest of that
+    # module serves the GA and stays with the reference
+    return np.sqrt(np.sum((a - b) ** 2))
 
 
 def _labels_to_device(clusters):
