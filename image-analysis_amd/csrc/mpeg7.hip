@@ -11,6 +11,7 @@
 #include "common.h"
 #include "../../include/imgan.h"
 #include <math.h>
+#include <atomic>
 
 namespace {
 
@@ -434,28 +435,70 @@ int make_hmmd(int nbins, HmmdTab* T) {
 
 extern "C" size_t imgan_cld_scratch_bytes(int B) { return B < 1 ? 0 : (size_t)B * 64 * 4 * 8; }
 
-extern "C" int imgan_cld(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out, void* scratch,
-                         imgan_stream_t stream) {
-    IMGAN_REQUIRE(bgr && cld_out && scratch, "imgan_cld: null pointer");
-    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && B <= 65535, "imgan_cld: bad shape");
-    IMGAN_REQUIRE((long long)H * 8 < 0x7fffffffLL && (long long)W * 8 < 0x7fffffffLL, "imgan_cld: too large");
-    hipStream_t st = (hipStream_t)stream;
-    IMGAN_HIP(hipMemsetAsync(scratch, 0, imgan_cld_scratch_bytes(B), st));
+// the two launches of the colour layout; `sums` is device memory of imgan_cld_scratch_bytes(B)
+static int cld_run(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out,
+                   unsigned long long* sums, hipStream_t st, const char* what) {
+    IMGAN_HIP(hipMemsetAsync(sums, 0, imgan_cld_scratch_bytes(B), st));
     dim3 grid(1, 8 * CLD_PARTS, (unsigned)B);
     if (W % 4 == 0 && ((uintptr_t)bgr & 3) == 0)
-        hipLaunchKernelGGL(cld_sums_kernel<true>, grid, dim3(256), 0, st, bgr, H, W,
-                           (unsigned long long*)scratch);
+        hipLaunchKernelGGL(cld_sums_kernel<true>, grid, dim3(256), 0, st, bgr, H, W, sums);
     else
-        hipLaunchKernelGGL(cld_sums_kernel<false>, grid, dim3(256), 0, st, bgr, H, W,
-                           (unsigned long long*)scratch);
+        hipLaunchKernelGGL(cld_sums_kernel<false>, grid, dim3(256), 0, st, bgr, H, W, sums);
     DctTable T;
     for (int i = 0; i < 8; ++i) {
         double s = i == 0 ? sqrt(0.125) : 0.5;
         for (int j = 0; j < 8; ++j) T.c[i * 8 + j] = s * cos((M_PI / 8.0) * i * (j + 0.5));
     }
     hipLaunchKernelGGL(cld_finalise_kernel, dim3(B * 3), dim3(64), 0, st,
-                       (const unsigned long long*)scratch, B, cld_out, T);
-    return imgan::check_launch("imgan_cld");
+                       (const unsigned long long*)sums, B, cld_out, T);
+    return imgan::check_launch(what);
+}
+
+static int cld_check(const uint8_t* bgr, int B, int H, int W, const int32_t* cld_out) {
+    IMGAN_REQUIRE(bgr && cld_out, "imgan_cld: null pointer");
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && B <= 65535, "imgan_cld: bad shape");
+    IMGAN_REQUIRE((long long)H * 8 < 0x7fffffffLL && (long long)W * 8 < 0x7fffffffLL, "imgan_cld: too large");
+    return 0;
+}
+
+extern "C" int imgan_cld(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out, void* scratch,
+                         imgan_stream_t stream) {
+    if (int rc = cld_check(bgr, B, H, W, cld_out)) return rc;
+    IMGAN_REQUIRE(scratch, "imgan_cld: null scratch");
+    return cld_run(bgr, B, H, W, cld_out, (unsigned long long*)scratch, (hipStream_t)stream,
+                   "imgan_cld");
+}
+
+// ---- imgan_cld_static: the colour layout for callers that cannot allocate -------------------
+// The block sums of imgan_cld (u64 [B][64][4]) live in a file-scope device array instead of a
+// caller's workspace.  `scratch` below is the HOST-side stand-in of that array: it is never
+// handed to a kernel or a memset; the device address comes from hipGetSymbolAddress, once per
+// device (every GPU holds its own copy of the array at its own address).
+constexpr int CLD_STATIC_MAX_B = 1024;                       // 1024 images x 2 KiB = 2 MiB per GPU
+static __device__ __align__(256) unsigned long long scratch[(size_t)CLD_STATIC_MAX_B * 64 * 4];
+
+constexpr int CLD_MAX_DEVICES = 64;
+static std::atomic<unsigned long long*> g_cld_static_ptr[CLD_MAX_DEVICES];
+
+extern "C" int imgan_cld_static(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out,
+                                imgan_stream_t stream) {
+    if (int rc = cld_check(bgr, B, H, W, cld_out)) return rc;
+    if (B > CLD_STATIC_MAX_B)
+        return imgan::fail(imgan::E_RANGE, "imgan_cld_static: at most " +
+                                               std::to_string(CLD_STATIC_MAX_B) +
+                                               " images per call (static scratch); use imgan_cld");
+    int dev = -1;
+    IMGAN_HIP(hipGetDevice(&dev));
+    IMGAN_REQUIRE(dev >= 0 && dev < CLD_MAX_DEVICES, "imgan_cld_static: device ordinal out of range");
+    unsigned long long* ptr = g_cld_static_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {                                              // first call on this device
+        void* p = nullptr;
+        IMGAN_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        IMGAN_REQUIRE(p != nullptr, "imgan_cld_static: no device address for the static scratch");
+        ptr = (unsigned long long*)p;
+        g_cld_static_ptr[dev].store(ptr, std::memory_order_release);   // same value from every thread
+    }
+    return cld_run(bgr, B, H, W, cld_out, ptr, (hipStream_t)stream, "imgan_cld_static");
 }
 
 static int ehd_block_size(int H, int W) {

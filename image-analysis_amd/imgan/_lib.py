@@ -70,6 +70,7 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "imgan_cld": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_cld_scratch_bytes": (c_size_t, [c_int]),
+    "imgan_cld_static": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "imgan_ehd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_ehd_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "imgan_csd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -235,6 +235,16 @@ int imgan_dcd_stats(const uint8_t* lab, const int32_t* labels, const uint8_t* as
 int imgan_cld(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out, void* scratch,
               imgan_stream_t stream);
 size_t imgan_cld_scratch_bytes(int B);
+
+/* imgan_cld for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs, outputs and
+ * results as imgan_cld; the block sums that imgan_cld keeps in the caller's `scratch` live in a
+ * static device array of the library instead (2 KiB per image, 2 MiB per GPU, held until the
+ * process ends), so B <= 1024 (IMGAN_E_RANGE beyond).  Calls no hipMalloc / hipFree or any other
+ * allocating routine.  Every call on a GPU shares that GPU's array (cleared at the start of
+ * each call): calls that overlap on one GPU -- two streams, two threads -- race. */
+int imgan_cld_static(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out,
+                     imgan_stream_t stream);
 int imgan_ehd(const uint8_t* bgr, int B, int H, int W, int32_t* ehd_out, void* scratch,
               imgan_stream_t stream);
 size_t imgan_ehd_scratch_bytes(int B, int H, int W);
