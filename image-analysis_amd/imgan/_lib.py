@@ -24,6 +24,7 @@ SIGNATURES = {
     "imgan_bgr2lab_u8": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "imgan_bgr2gray_u8": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "imgan_median7_u8c3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "imgan_median_u8c3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "imgan_slic_grid_host": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_slic_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "imgan_slic_init": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -70,15 +70,19 @@ def bgr2gray(bgr, out=None):
     return out
 
 
-def median7(bgr, out=None):
-    """cv2.medianBlur(bgr, 7) (rag_segmentation.py:11)."""
+def median_blur(bgr, ksize=7, out=None):
+    """cv2.medianBlur(bgr, ksize), ksize 3, 5 or 7 (rag_segmentation.py:11 uses 7)."""
     _require_gpu()
     img = as_batch(_dev(bgr, torch.uint8, "bgr"))
     if out is None:
         out = torch.empty_like(bgr)
     B, H, W, _ = img.shape
-    check(lib.imgan_median7_u8c3(_ptr(img), _ptr(out), B, H, W, _stream()))
+    check(lib.imgan_median_u8c3(_ptr(img), _ptr(out), B, H, W, int(ksize), _stream()))
     return out
+
+
+def median7(bgr, out=None):
+    return median_blur(bgr, 7, out)
 
 
 def slic_grid(H, W, num_clusters, step=None):

@@ -32,10 +32,11 @@ class RAGSegmentation(object):
         # rag_segmentation.py:10-19
         if not isinstance(image, np.ndarray):
             raise ValueError("Image value is None. Probably not loaded correctly!")
-        if median_blur != 7:
-            raise ValueError("only the 7x7 median of the reference pipeline is built (median_blur=7)")
+        if median_blur not in (3, 5, 7):
+            raise ValueError("median_blur must be 3, 5 or 7 (cv2.medianBlur takes any odd size; the "
+                             "reference pipeline uses 7)")
         dev = torch.from_numpy(np.ascontiguousarray(image)).cuda()
-        self._dev_image = ops.median7(dev)                         # cv2.medianBlur(image, 7)
+        self._dev_image = ops.median_blur(dev, median_blur)       # cv2.medianBlur(image, median_blur)
         self._dev_lab = ops.bgr2lab(self._dev_image)
         image = self._dev_image.cpu().numpy()
         self.image_lab = self._dev_lab.cpu().numpy()

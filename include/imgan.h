@@ -50,6 +50,10 @@ int imgan_bgr2gray_u8(const uint8_t* bgr, uint8_t* gray, int64_t npix, imgan_str
  * replicated border). */
 int imgan_median7_u8c3(const uint8_t* src, uint8_t* dst, int B, int H, int W,
                        imgan_stream_t stream);
+/* cv2.medianBlur(image, ksize) for the other kernel sizes RAGSegmentation's median_blur argument
+ * may carry (rag_segmentation.py:10-11): ksize = 3, 5 or 7. */
+int imgan_median_u8c3(const uint8_t* src, uint8_t* dst, int B, int H, int W, int ksize,
+                      imgan_stream_t stream);
 
 /* ---- SLIC ------------------------------------------------------------------
  * imgan_slic_grid: slic.py:29,33 (step) and :42-43 (seed grid); host only.

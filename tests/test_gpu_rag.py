@@ -26,6 +26,31 @@ def test_median7_matches_oracle(shape):
     assert np.array_equal(ops.median7(torch.from_numpy(const).cuda()).cpu().numpy(), const)
 
 
+@pytest.mark.parametrize("ksize", [3, 5, 7])
+@pytest.mark.parametrize("shape", [(150, 300), (131, 257), (64, 128), (1, 1), (3, 200), (70, 33)])
+def test_median_sizes_tiles_and_borders(ksize, shape):
+    """Several 128 x 64 tiles, widths with and without the dword-aligned fast path, images
+    smaller than the window, a batch, and value patterns with many ties (0 / 255 / plateaus)."""
+    torch = _torch()
+    from imgan import ops
+    from oracle.color import median_blur
+    rng = np.random.RandomState(ksize * 100 + shape[1])
+    imgs = np.stack([rng.randint(0, 256, shape + (3,)), rng.randint(0, 2, shape + (3,)) * 255,
+                     (rng.randint(0, 256, shape + (3,)) // 64) * 64]).astype(np.uint8)
+    got = ops.median_blur(torch.from_numpy(imgs).cuda(), ksize).cpu().numpy()
+    for b in range(3):
+        assert np.array_equal(got[b], median_blur(imgs[b], ksize)), (b, ksize, shape)
+
+
+def test_median_rejects_other_sizes():
+    torch = _torch()
+    from imgan import ops
+    img = torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda")
+    for ksize in (1, 4, 9):
+        with pytest.raises(ValueError):
+            ops.median_blur(img, ksize)
+
+
 @pytest.mark.parametrize("H,W,K,c", [(213, 320, 200, 0.65), (120, 160, 60, 0.65),
                                      (101, 157, 40, 2.0), (96, 128, 300, 0.6)])
 def test_rag_pipeline_matches_oracle(H, W, K, c):
