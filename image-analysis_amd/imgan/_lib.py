@@ -50,6 +50,8 @@ SIGNATURES = {
     "imgan_rag_merge_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_i64, c_double,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),
+    "imgan_rag_merge_device": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_double,
+                                       c_void_p, c_void_p, c_void_p]),
     "imgan_relabel_lut": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p]),
     "imgan_paint_means": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p]),
     "imgan_cc_label": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

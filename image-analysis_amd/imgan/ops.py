@@ -221,6 +221,57 @@ def rag_accumulate(img, labels, K, want_edges=True, edge_cap=None):
     return sums, edges
 
 
+class RagPlan(object):
+    """The RAG step of a device-resident batch without leaving the GPU: per-label sums + adjacency
+    (rag_segmentation.py:38-74), then the merge of :77-184 by one workgroup per image
+    (imgan_rag_merge_device), which writes the relabel tables in place.  Nothing synchronises;
+    `status` (int32 [B], device) is nonzero for an image the device merge had to leave to the host
+    (edge set overflowed, more than 16,384 edges): finish() deals with those."""
+
+    MAX_K = 4096
+
+    def __init__(self, B, K, edge_cap=None, device=None):
+        _require_gpu()
+        self.B, self.K = int(B), int(K)
+        if self.K > self.MAX_K:
+            raise OverflowError("RagPlan: more than %d labels per image; use rag_accumulate + "
+                                "rag_merge_batch" % self.MAX_K)
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        self.cap = int(edge_cap or _pow2_at_least(16 * max(self.K, 64)))
+        self.sums = torch.empty((self.B, self.K, 4), dtype=torch.int64, device=dev)
+        self.table = torch.empty((self.B, self.cap), dtype=torch.int64, device=dev)
+        self.overflow = torch.empty(self.B, dtype=torch.int32, device=dev)
+        self.lut = torch.zeros((self.B, self.K), dtype=torch.int32, device=dev)
+        self.status = torch.zeros(self.B, dtype=torch.int32, device=dev)
+
+    def run(self, img, labels, c_factor):
+        """img u8 [B,H,W,3], labels int32 [B,H,W] -> (lut int32 [B,K], status int32 [B]), both on
+        the device, enqueued on the current stream."""
+        img = as_batch(_dev(img, torch.uint8, "img"))
+        _dev(labels, torch.int32, "labels")
+        B, H, W, _ = img.shape
+        if B != self.B or tuple(labels.shape) != (B, H, W):
+            raise ValueError("batch does not match the plan")
+        self.sums.zero_()
+        self.table.zero_()
+        self.overflow.zero_()
+        check(lib.imgan_rag_accumulate(_ptr(img), _ptr(labels), B, H, W, self.K, _ptr(self.sums),
+                                       _ptr(self.table), self.cap, _ptr(self.overflow), _stream()))
+        check(lib.imgan_rag_merge_device(_ptr(self.sums), _ptr(self.table), self.cap,
+                                         _ptr(self.overflow), B, self.K, float(c_factor),
+                                         _ptr(self.lut), _ptr(self.status), _stream()))
+        return self.lut, self.status
+
+    def finish(self, img, labels, c_factor):
+        """Synchronises once and redoes, through the host merge, the images whose status is
+        nonzero (none in practice).  Returns the number of images redone."""
+        bad = torch.nonzero(self.status).flatten().tolist()
+        for b in bad:
+            sums, edges = rag_accumulate(img[b:b + 1], labels[b:b + 1], self.K)
+            self.lut[b] = torch.from_numpy(rag_merge_batch(self.K, edges, sums, c_factor)[0]).to(self.lut.device)
+        return len(bad)
+
+
 def rag_merge_batch(K, edges, sums, c_factor, threads=16):
     """The merge of rag_segmentation.py:77-184 for every image of a batch (means mode; host C++
     in the library, the images spread over `threads` host threads).  sums: the [B,K,4] tensor of

@@ -106,24 +106,36 @@ class FullPipeline(object):
 class RagPipeline(object):
     """Batch form of RAGSegmentation's sequence (rag_segmentation.py:10-25, 38-184) for
     device-resident batches (BASELINE.json configs[2]): median 7x7 -> Lab -> SLIC -> per-label
-    means + adjacency -> MST merge with the leave-one-out cut (host C++, a few threads) ->
-    relabel.  Returns the merged label maps (int32, 0 = the unlabelled border)."""
+    means + adjacency -> MST merge with the leave-one-out cut -> relabel.  Every stage is a kernel
+    of libimgan_hip.so on the current stream; with at most 4096 labels per image the merge runs
+    on the device too (ops.RagPlan) and a step enqueues without a host round trip.  Returns the
+    merged label maps (int32, 0 = the unlabelled border) and the relabel tables."""
 
-    def __init__(self, B, H, W, num_clusters, colour_weight=15, num_iter=10, c_factor=0.65):
-        self.B, self.H, self.W, self.K = int(B), int(H), int(W), int(num_clusters)
+    def __init__(self, B, H, W, num_clusters, colour_weight=15, num_iter=10, c_factor=0.65,
+                 median_blur=7):
+        self.B, self.H, self.W = int(B), int(H), int(W)
         self.cw, self.num_iter, self.c_factor = colour_weight, int(num_iter), float(c_factor)
+        self.ksize = int(median_blur)
         self.slic = ops.SlicPlan(B, H, W, num_clusters)
+        # SLIC hands out n = nx * ny labels, which can exceed the requested count at small steps
+        # (39 x 39, K = 96 -> S = 3, n = 144): size the tables for both
+        self.K = max(int(num_clusters), self.slic.n)
         dev = self.slic.device
         self.blur = torch.empty((self.B, self.H, self.W, 3), dtype=torch.uint8, device=dev)
         self.lab = torch.empty_like(self.blur)
+        self.merged = torch.empty((self.B, self.H, self.W), dtype=torch.int32, device=dev)
+        self.rag = ops.RagPlan(B, self.K) if self.K <= ops.RagPlan.MAX_K else None
         self.stage_events = {}
         self.host_ms = {}
+        self.redone = 0
 
     _timed = FullPipeline._timed
 
-    def step(self, bgr, timed=False):
+    def step(self, bgr, timed=False, check=True):
+        """check=False leaves the status words unread (no synchronisation at all): the caller
+        looks at self.rag.status later, as bench.py does after its timed loop."""
         import time
-        self._timed("median7", timed, lambda: ops.median7(bgr, out=self.blur))
+        self._timed("median", timed, lambda: ops.median_blur(bgr, self.ksize, out=self.blur))
         self._timed("bgr2lab", timed, lambda: ops.bgr2lab(self.blur, out=self.lab))
         if self.num_iter > 1:
             self.slic.seed(self.lab)
@@ -137,16 +149,26 @@ class RagPipeline(object):
             else:
                 self.slic.round(self.lab, self.cw, first=(it == 1))
         labels = self.slic.labels
-        t0 = time.perf_counter()
-        sums, edges = ops.rag_accumulate(self.lab, labels, self.K)      # synchronises (edge lists)
-        t1 = time.perf_counter()
-        luts = ops.rag_merge_batch(self.K, edges, sums, self.c_factor)
-        t2 = time.perf_counter()
-        merged = self._timed("relabel", timed,
-                             lambda: ops.relabel(labels, torch.from_numpy(luts).to(labels.device)))
-        if timed:
-            self.host_ms.setdefault("rag_accumulate+edge lists", []).append((t1 - t0) * 1e3)
-            self.host_ms.setdefault("host merge", []).append((t2 - t1) * 1e3)
-        return merged, luts
+        if self.rag is not None:
+            luts, _ = self._timed("rag_accumulate+merge", timed,
+                                  lambda: self.rag.run(self.lab, labels, self.c_factor))
+            if check:
+                self.redone += self.rag.finish(self.lab, labels, self.c_factor)
+        else:                                   # more labels than the device merge holds in LDS
+            t0 = time.perf_counter()
+            sums, edges = ops.rag_accumulate(self.lab, labels, self.K)      # synchronises
+            t1 = time.perf_counter()
+            luts = torch.from_numpy(ops.rag_merge_batch(self.K, edges, sums, self.c_factor)).to(labels.device)
+            if timed:
+                self.host_ms.setdefault("rag_accumulate+edge lists", []).append((t1 - t0) * 1e3)
+                self.host_ms.setdefault("host merge", []).append((time.perf_counter() - t1) * 1e3)
+        self._timed("relabel", timed, lambda: check_call_relabel(labels, luts, self.merged))
+        return self.merged, luts
 
     stage_times_ms = FullPipeline.stage_times_ms
+
+
+def check_call_relabel(labels, luts, out):
+    check(lib.imgan_relabel_lut(ops._ptr(labels), ops._ptr(luts), ops._ptr(out), labels.shape[0],
+                                labels[0].numel(), luts.shape[1], ops._stream()))
+    return out

@@ -149,6 +149,19 @@ int imgan_rag_merge_host_batch(const int32_t* means, int B, int K, const int32_t
                                const int64_t* edge_offsets, double c_factor, int32_t* lut_out,
                                int threads);
 
+/* The same merge (means mode, relabel table only) on the device, one workgroup per image, for
+ * batches that stay on the GPU: reads the sums and the edge hash sets exactly as
+ * imgan_rag_accumulate left them (DEVICE pointers, same B, K, edge_cap, overflow) and writes
+ * lut_out int32 [B][K].  K <= 4096 (IMGAN_E_RANGE beyond: use the host form).  status: int32 [B]
+ * (device), 0 = done; nonzero = this image's table was not written and the caller finishes it
+ * with imgan_rag_merge_host (1: more than 16,384 edges, 2: an edge endpoint >= K, 3: the edge set
+ * had overflowed).  The cut (rag_segmentation.py:163-170) is evaluated from the sum and the sum
+ * of squares of the tree's weights in double-double arithmetic; a weight within ~1e-15 of its
+ * threshold may fall on the other side than numpy's two-pass float64 mean / std puts it. */
+int imgan_rag_merge_device(const uint64_t* sums, const uint64_t* edges, int64_t edge_cap,
+                           const int32_t* overflow, int B, int K, double c_factor,
+                           int32_t* lut_out, int32_t* status, imgan_stream_t stream);
+
 /* rag_segmentation.py:175-182: out[p] = lut[labels[p]] (labels[p] < 0 or >= K -> 0).
  * lut: int32 [B][K] device. */
 int imgan_relabel_lut(const int32_t* labels, const int32_t* lut, int32_t* out, int B,

@@ -164,4 +164,87 @@ def test_rag_pipeline_batch_class_matches_oracle():
         want = o.concat_similar_regs(o.find_edges(o.neighbours_regions(cl), o.slic_mean_lab(cl)),
                                      cl, 0.65)[0]
         assert np.array_equal(merged[b].astype(np.float64), want), b
-    assert set(pipe.stage_times_ms()) >= {"median7", "bgr2lab", "slic_assign", "relabel"}
+    assert set(pipe.stage_times_ms()) >= {"median", "bgr2lab", "slic_assign", "rag_accumulate+merge", "relabel"}
+    assert pipe.redone == 0 and int(pipe.rag.status.abs().sum()) == 0      # merged on the device
+
+
+def _device_merge(torch, K, means, edge_lists, c, cap=None):
+    """imgan_rag_merge_device on hand-made sums / edge hash sets (the layout imgan_rag_accumulate
+    leaves): returns (luts, status)."""
+    from imgan import ops
+    from imgan._lib import lib, check
+    B = len(edge_lists)
+    plan = ops.RagPlan(B, K, edge_cap=cap)
+    sums = np.zeros((B, K, 4), dtype=np.int64)
+    sums[:, :, :3] = means * 7                      # floor(7 m / 7) = m
+    sums[:, :, 3] = 7
+    table = np.zeros((B, plan.cap), dtype=np.uint64)
+    rng = np.random.RandomState(1)
+    for b, uv in enumerate(edge_lists):
+        keys = ((uv[:, 0].astype(np.uint64) + 1) << np.uint64(32)) | (uv[:, 1].astype(np.uint64) + 1)
+        slots = rng.choice(plan.cap, len(keys), replace=False)      # any slot: the merge only scans
+        table[b, slots] = keys
+    plan.sums.copy_(torch.from_numpy(sums))
+    plan.table.copy_(torch.from_numpy(table.view(np.int64)))
+    plan.overflow.zero_()
+    check(lib.imgan_rag_merge_device(ops._ptr(plan.sums), ops._ptr(plan.table), plan.cap,
+                                     ops._ptr(plan.overflow), B, K, float(c), ops._ptr(plan.lut),
+                                     ops._ptr(plan.status), ops._stream()))
+    return plan.lut.cpu().numpy(), plan.status.cpu().numpy()
+
+
+@pytest.mark.parametrize("K,levels,c", [(50, 256, 0.65), (300, 8, 0.65), (2000, 256, 0.65), (4096, 32, 2.0),
+                                        (700, 3, 0.1), (5, 256, 0.65), (1, 256, 0.65)])
+def test_device_merge_equals_host_merge(K, levels, c):
+    """Random planar-ish graphs (grid neighbours + diagonals, some vertices isolated), colours
+    quantised to `levels` values so that equal weights are common: relabel tables of the device
+    merge against imgan_rag_merge_host (itself checked against the oracle and the golden files)."""
+    torch = _torch()
+    from imgan import ops
+    rng = np.random.RandomState(K + levels)
+    B = 3
+    side = max(1, int(np.sqrt(K)))
+    means = (rng.randint(0, levels, (B, K, 3)) * (256 // levels)).astype(np.int64)
+    edge_lists = []
+    for b in range(B):
+        uv = set()
+        for v in range(K):
+            if rng.rand() < 0.05:
+                continue                                     # an isolated vertex (empty label id)
+            for d in (1, side, side + 1, side - 1):
+                if v + d < K and d > 0 and rng.rand() < 0.8:
+                    uv.add((v, v + d))
+        edge_lists.append(np.array(sorted(uv), dtype=np.int64).reshape(-1, 2))
+    luts, status = _device_merge(torch, K, means, edge_lists, c)
+    assert (status == 0).all()
+    for b in range(B):
+        want = ops.rag_merge_host(K, edge_lists[b], c, means=means[b])["lut"]
+        assert np.array_equal(luts[b], want), b
+
+
+def test_device_merge_hands_over_what_it_cannot_hold():
+    """More than 16,384 edges, or an edge set that overflowed: status says so, and
+    RagPlan.finish() redoes the image through the host merge."""
+    torch = _torch()
+    from imgan import ops
+    K = 4096
+    rng = np.random.RandomState(3)
+    means = rng.randint(0, 256, (1, K, 3)).astype(np.int64)
+    u = rng.randint(0, K - 1, 40000)
+    v = np.minimum(u + 1 + rng.randint(0, 50, 40000), K - 1)
+    uv = np.unique(np.stack([u, v], 1)[u < v], axis=0)
+    assert len(uv) > 16384
+    luts, status = _device_merge(torch, K, means, [uv], 0.65, cap=1 << 17)
+    assert status[0] == 1
+
+
+def test_rag_pipeline_small_step_more_labels_than_requested():
+    """39 x 39 with K = 96 gives S = 3 and n = 144 labels > K (the reference dies with a KeyError
+    in find_edges there): the batch path sizes its tables for n and merges all of them."""
+    torch = _torch()
+    from imgan.pipeline import RagPipeline
+    img = voronoi_image(39, 39, 6, seed=9)
+    pipe = RagPipeline(1, 39, 39, 96)
+    assert pipe.slic.n == 144 and pipe.K == 144
+    merged, luts = pipe.step(torch.from_numpy(img[None]).cuda())
+    assert int(merged.max()) >= 1 and pipe.redone == 0

@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 steps = 3
 for _ in range(steps):
-    merged, luts = pipe.step(bgr, timed=True)
+    merged, luts = pipe.step(bgr, timed=True, check=False)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 for k, v in pipe.stage_times_ms().items():
