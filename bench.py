@@ -57,21 +57,6 @@ def synth_batch(B, H, W, K, seed, device):
     return out
 
 
-def measured_traffic(B, H, W, K):
-    """HBM bytes per slic_assign_kernel launch from the rocprofv3 PMC passes committed under
-    profiles/ (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE),
-    scaled to this batch; null when no pass exists for this image size."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        t = json.load(f)
-    e = t.get("%dx%d_K%d" % (W, H, K), {}).get("slic_assign_kernel")
-    if not e:
-        return None
-    return int(e["bytes_per_px"] * B * H * W)
-
-
 def cpu_baseline_numpy(H, W, K, cw, k=8):
     """The numpy oracle, which keeps the reference's own cost structure (per-centre window ops
     + per-label full-image scans, slic.py:88-126; per-segment Lloyd loops + per-colour
@@ -148,6 +133,191 @@ def cpu_baseline(H, W, K, cw, k=8):
     return fast, slow
 
 
+def cpu_baseline_rag(cw=15):
+    """CPU leg of configs[2] on a bounded sample: one 1920x1080 quarter of a 4K frame (K = 500,
+    the same S = 64 grid), one thread: numpy median on a 270-row band (scaled x4), numpy Lab, the C
+    restatement of SLIC (oracle/c), the numpy oracle of rag_segmentation.py:38-184."""
+    from oracle.synth import voronoi_image
+    from oracle.color import bgr2lab_u8, median_blur
+    from oracle import c_oracle
+    from oracle.rag_ref import RAGOracle
+    H, W, K = 1080, 1920, 500
+    img = voronoi_image(H, W, K, seed=4321)
+    t0 = time.perf_counter()
+    median_blur(img[:276], 7)
+    t_med = (time.perf_counter() - t0) * H / 270.0
+    t0 = time.perf_counter()
+    lab = bgr2lab_u8(img)
+    t_lab = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    labels, _ = c_oracle.slic_run(lab, K, cw, 10)
+    t_slic = time.perf_counter() - t0
+    ora = RAGOracle.__new__(RAGOracle)
+    ora.image, ora.image_lab, ora.image_mean, ora.slic_clust_num = img, lab, img.copy(), K
+    t0 = time.perf_counter()
+    cl = labels.astype(np.float64)
+    col = ora.slic_mean_lab(cl, nchange=True)
+    ng = ora.neighbours_regions(cl)
+    ora.concat_similar_regs(ora.find_edges(ng, col), cl, c_factor=0.65)
+    t_rag = time.perf_counter() - t0
+    full = t_med + t_lab + t_slic + t_rag
+    return {"value": round(H * W / 1e6 / full, 3), "unit": "megapixels/sec", "cores": 1, "kind": "port",
+            "sample": "one 1920x1080 quarter of a 4K frame, K=500 (S=64 as at 4K), 1 thread: numpy "
+                      "median %.1f s (270-row band timed, scaled) + numpy Lab %.2f s + C SLIC %.1f s + "
+                      "numpy RAG means / adjacency / merge %.2f s" % (t_med, t_lab, t_slic, t_rag)}
+
+
+def cpu_baseline_mosaic(cw=15, k=8):
+    """CPU leg of configs[4] on a bounded sample: a 2048x2048 tile of the mosaic (K = 781, the same
+    S = 73 grid), one thread: numpy Lab + the C restatement of SLIC and of the dominant colours
+    of every superpixel."""
+    from oracle.synth import voronoi_image
+    from oracle.color import bgr2lab_u8
+    from oracle import c_oracle
+    H = W = 2048
+    K = 781
+    img = voronoi_image(H, W, K, seed=99)
+    t0 = time.perf_counter()
+    lab = bgr2lab_u8(img)
+    t_lab = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    c_oracle.path_batch(lab[None], K, cw, 10, k, 1)
+    t_c = time.perf_counter() - t0
+    return {"value": round(H * W / 1e6 / (t_lab + t_c), 3), "unit": "megapixels/sec", "cores": 1,
+            "kind": "port",
+            "sample": "one 2048x2048 tile of the mosaic, K=781 (S=73 as at 16384^2), 1 thread: numpy Lab "
+                      "%.2f s + C SLIC and dominant colours k=%d of every superpixel %.1f s" % (t_lab, k, t_c)}
+
+
+def roofline_line(kernel, ms, bytes_px, npix, traffic=None, profile=None, note=None, bound=None,
+                  launches=1):
+    """Priced against the HBM roofline (nothing on this path is a contraction); `limited_by` names
+    what the kernel is measured to be bound by when that is not HBM bandwidth."""
+    ach = bytes_px * npix / (ms * 1e-3) / 1e9
+    d = {"bound": "hbm", "limited_by": bound or "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+         "launch_ms": round(ms, 4), "bytes_per_px": bytes_px,
+         "algorithmic_bytes_per_launch": int(bytes_px * npix), "launches_per_step": launches}
+    if profile:
+        d["profile"] = profile
+    if note:
+        d["note"] = note
+    return d
+
+
+def pmc_traffic(key, kernel, npix):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        e = json.load(f).get(key, {}).get(kernel)
+    return int(e["bytes_per_px"] * npix) if e else None
+
+
+def run_config_rag(steps, warmup):
+    """configs[2]: 16 x 3840x2160, K = 2000, median 7 + Lab + SLIC + RAG merge + relabel."""
+    from imgan.pipeline import RagPipeline
+    B, H, W, K = 16, 2160, 3840, 2000
+    bgr = synth_batch(B, H, W, K, 4321, "cuda")
+    pipe = RagPipeline(B, H, W, K)
+    for _ in range(warmup):
+        pipe.step(bgr, check=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step(bgr, timed=True, check=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    redone = pipe.rag.finish(pipe.lab, pipe.slic.labels, pipe.c_factor) if pipe.rag is not None else 0
+    ms = pipe.stage_times_ms()
+    npix = B * H * W
+    prof = "profiles/r02_rag4k_kernel_summary.txt"
+    path_bytes = 6 + 6 + 63 + 7 + 8
+    rec = {"config": "configs[2]: %d x %dx%d BGR, K=%d (n=%d, S=%d), median 7x7 + Lab + SLIC (9 rounds) "
+                     "+ per-label means and adjacency + MST merge (c=0.65, on the device) + relabel" %
+                     (B, W, H, K, pipe.slic.n, pipe.slic.S),
+           "value": round(npix * steps / dt / 1e6, 2), "unit": "megapixels/sec",
+           "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "images_redone_on_host": int(redone),
+           "roofline": roofline_line("slic_assign_kernel", ms["slic_assign"], 7, npix,
+                                     traffic=pmc_traffic("3840x2160_K2000", "slic_assign_kernel", npix),
+                                     profile=prof, launches=9,
+                                     note="largest share of the step (9 launches)"),
+           "roofline_kernels": [
+               roofline_line("median_bits_kernel<7>", ms["median"], 6, npix, profile=prof, bound="valu",
+                             traffic=pmc_traffic("3840x2160_K2000", "median_bits_kernel", npix),
+                             note="bit-sliced selection, instruction bound by design"),
+               roofline_line("bgr2lab_kernel", ms["bgr2lab"], 6, npix, profile=prof),
+               roofline_line("rag_accumulate_kernel + rag_merge_kernel", ms["rag_accumulate+merge"], 7,
+                             npix, profile=prof, bound="atomics/latency"),
+               roofline_line("relabel_kernel", ms["relabel"], 8, npix, profile=prof)],
+           "path": {"bytes_per_px": path_bytes,
+                    "achieved": round(path_bytes * npix * steps / dt / 1e9, 1), "unit": "GB/s",
+                    "frac": round(path_bytes * npix * steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "SURVEY 8d: 6 median + 6 Lab + 63 SLIC + 7 RAG + 8 relabel"},
+           "cpu_baseline": cpu_baseline_rag()}
+    del pipe, bgr
+    torch.cuda.empty_cache()
+    return rec
+
+
+def run_config_mosaic(steps, warmup):
+    """configs[4] on one GPU: one 16384x16384 mosaic, K = 50,000, descriptors per superpixel."""
+    from imgan.pipeline import FullPipeline
+    B, H, W, K = 1, 16384, 16384, 50000
+    bgr = synth_batch(B, H, W, K, 99, "cuda")
+    pipe = FullPipeline(B, H, W, K, colour_weight=15, num_iter=10, dominant=8)
+    for _ in range(warmup):
+        pipe.step(bgr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step(bgr, timed=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = pipe.stage_times_ms()
+    npix = B * H * W
+    t_bar = pipe.mean_lloyd_rounds()
+    dcd_bytes = round(8.0 * t_bar + 13.0, 1)
+    prof = "profiles/r02_mosaic_kernel_summary.txt"
+    path_bytes = 6 + 63 + pipe.descriptor_bytes_per_px() + dcd_bytes
+    rec = {"config": "configs[4] (one GPU's share): %d x %dx%d BGR, K=%d (n=%d, S=%d), Lab + SLIC + "
+                     "CLD / EHD / CSD + dominant colours k=8 of every superpixel (%.1f Lloyd rounds per pixel)" %
+                     (B, W, H, K, pipe.n, pipe.slic.S, t_bar),
+           "value": round(npix * steps / dt / 1e6, 2), "unit": "megapixels/sec",
+           "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "dcd_segments_at_round_cap": pipe.segments_at_round_cap(),
+           "roofline": roofline_line("dcd_segment_kernel", ms["dcd_segments"], dcd_bytes, npix, profile=prof,
+                                     bound="valu/lds",
+                                     note="SURVEY 8d figure 8*T+13*P; the Lloyd rounds run in LDS, "
+                                          "compulsory HBM traffic is 8 B/px"),
+           "roofline_kernels": [roofline_line("slic_assign_kernel", ms["slic_assign"], 7, npix, profile=prof,
+                                              launches=9),
+                                roofline_line("bgr2lab_kernel", ms["bgr2lab"], 6, npix, profile=prof)],
+           "path": {"bytes_per_px": round(path_bytes, 1),
+                    "achieved": round(path_bytes * npix * steps / dt / 1e9, 1), "unit": "GB/s",
+                    "frac": round(path_bytes * npix * steps / dt / 1e9 / HBM_PEAK_GBS, 4)},
+           "cpu_baseline": cpu_baseline_mosaic()}
+    del pipe, bgr
+    torch.cuda.empty_cache()
+    return rec
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` on its own: start N ranks (one per GPU, RCCL) as a child job and
+    pass its output and exit code on.  Nothing in this process has touched the GPU yet."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,7 +328,16 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--clusters", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the configs[2] / configs[4] sub-records (N = 1 only)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        rehearsal = os.environ.get("IMGAN_BENCH_REHEARSAL") == "1"   # all ranks on device 0, gloo
+        if torch.cuda.device_count() < args.gpus and not rehearsal:  # counting does not initialise HIP
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" %
+                             (args.gpus, torch.cuda.device_count()))
+        raise SystemExit(spawn_ranks(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -214,34 +393,28 @@ def main():
 
     if rank == 0:
         npix = B * H * W
+        key = "%dx%d_K%d" % (W, H, K)
+        prof = "profiles/r02_bench_kernel_summary.txt"
         stage_ms = pipe.stage_times_ms()           # HIP events on the launch stream, per C call
-        avg_ms = stage_ms["slic_assign"]
-        algo = SLIC_ROUND_BYTES_PER_PX * npix
-        achieved = algo / (avg_ms * 1e-3) / 1e9
         # mean Lloyd rounds per pixel (a segment stops at its own round): the T of SURVEY 8d
         t_bar = pipe.mean_lloyd_rounds()
-        traffic = measured_traffic(B, H, W, K)
-
-        def line(kernel, ms, bytes_px, bound="hbm", note=None):
-            ach = bytes_px * npix / (ms * 1e-3) / 1e9
-            d = {"kernel": kernel, "bound": bound, "launch_ms": round(ms, 4), "bytes_per_px": bytes_px,
-                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": round(ach / HBM_PEAK_GBS, 4)}
-            if note:
-                d["note"] = note
-            return d
-
-        dcd_survey = 8.0 * t_bar + 13.0
+        dcd_survey = round(8.0 * t_bar + 13.0, 1)
+        desc_bytes = pipe.descriptor_bytes_per_px()
         others = [
-            line("bgr2lab_kernel", stage_ms["bgr2lab"], 6),
-            line("dcd_segment_kernel (+bbox, features)", stage_ms["dcd"], round(dcd_survey, 1),
-                 note="SURVEY 8d figure 8*T+13*P with T=%.1f measured rounds/px, P=1; the Lloyd "
-                      "rounds run in LDS, compulsory HBM traffic is 8 B/px (VALU/LDS bound)" % t_bar),
-            line("csd_kernel", stage_ms["csd"], 3),
-            line("cld_sums_kernel (+finalise)", stage_ms["cld"], 3),
-            line("ehd_sums_kernel (+classify)", stage_ms["ehd"], 3),
+            roofline_line("slic_assign_kernel", stage_ms["slic_assign"], SLIC_ROUND_BYTES_PER_PX, npix,
+                          traffic=pmc_traffic(key, "slic_assign_kernel", npix), profile=prof,
+                          launches=num_iter - 1,
+                          note="moves the most HBM bytes of the step (9 x 7 B/px); instruction-issue bound"),
+            roofline_line("bgr2lab_kernel", stage_ms["bgr2lab"], 6, npix, profile=prof,
+                          traffic=pmc_traffic(key, "bgr2lab_kernel", npix)),
+            roofline_line("csd_kernel", stage_ms["csd"], 3, npix, profile=prof,
+                          traffic=pmc_traffic(key, "csd_kernel", npix)),
+            roofline_line("cld_sums_kernel (+finalise)", stage_ms["cld"], 3, npix, profile=prof,
+                          traffic=pmc_traffic(key, "cld_sums_kernel", npix)),
+            roofline_line("ehd_sums_kernel (+classify)", stage_ms["ehd"], 3, npix, profile=prof,
+                          traffic=pmc_traffic(key, "ehd_sums_kernel", npix)),
         ]
-        path_bytes_px = 6 + 63 + 9 + dcd_survey
+        path_bytes_px = 6 + 63 + desc_bytes + dcd_survey
         out = {
             "metric": "megapixels/sec (SLIC+RAG+MPEG-7) at 1/2/4/8 GPUs; % HBM roofline",
             "value": round(world * npix * args.steps / dt / 1e6, 2),
@@ -256,21 +429,30 @@ def main():
                                     "Lab + SLIC + CLD + EHD + CSD(256) + DCD(k=8 per superpixel, "
                                     "%.1f Lloyd rounds per pixel on chip)" % t_bar),
                        "global_batch": B * world, "parallelism": "batch-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "slic_assign_kernel", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "launch_ms": round(avg_ms, 4),
-                         "algorithmic_bytes_per_launch": algo,
-                         "launches_per_step": num_iter - 1},
+            # the dominant kernel by time; the two tiers of dcd_segment_kernel (one launch each, the
+            # second for the few superpixels too large for the first) are one pass over the segments
+            "roofline": roofline_line(
+                "dcd_segment_kernel", stage_ms["dcd_segments"], dcd_survey, npix,
+                traffic=pmc_traffic(key, "dcd_segment_kernel", npix), profile=prof, bound="valu/lds",
+                note="largest share of the step time.  Algorithmic bytes = SURVEY 8d's streaming figure "
+                     "8*T + 13*P B/px with T = %.1f measured Lloyd rounds per pixel, P = 1; the rounds run "
+                     "in LDS, so the HBM traffic it must move is 8 B/px and the kernel is VALU / LDS "
+                     "bound" % t_bar),
             "roofline_kernels": others,
+            "dcd_segments_at_round_cap": pipe.segments_at_round_cap(),
             "path": {"bytes_per_px": round(path_bytes_px, 1),
                      "achieved": round(path_bytes_px * npix * args.steps / dt / 1e9 * 1.0, 1),
                      "unit": "GB/s", "frac": round(path_bytes_px * npix * args.steps / dt / 1e9
                                                    / HBM_PEAK_GBS, 4),
                      "note": "whole step against SURVEY 8d's algorithmic bytes "
-                             "(6 Lab + 63 SLIC + 9 CLD/EHD/CSD + DCD)"},
+                             "(6 Lab + 63 SLIC + %g CLD/EHD/CSD + DCD)" % desc_bytes},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["cpu_baseline_numpy"] = cpu_baseline(H, W, K, cw)
+        if world == 1 and not args.no_configs:
+            del pipe, bgr, index, pending, image_rows, region_rows
+            torch.cuda.empty_cache()
+            out["configs"] = [run_config_rag(max(args.steps, 3), 1), run_config_mosaic(2, 1)]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -454,13 +454,20 @@ class DcdPlan(object):
         self.rounds_run = 0          # streaming rounds issued for the large segments
         self.big_segments = 0
 
+    # pixels the LDS-resident kernel holds per segment (its large tier, dcd_seg.hip)
+    LDS_CAPACITY = 22528
+
     def kmeans(self, lab, labels, centres, seed=None, max_rounds=1000, check_every=1,
-               streaming_only=False, boxed=False):
+               streaming_only=False, boxed=False, max_segment_px=None):
         """Runs every segment's Lloyd loop to the reference's stop rule.
         centres: float32 [B,nseg,k,3], updated in place; with seed is not None they are
         sampled on the device (hash rule of imgan_dcd_init_hash), otherwise they must hold
         the initial centres.  boxed: self.bbox already holds the bounding boxes of `labels`
-        (SlicPlan.round(..., bbox=self.bbox) on the round that made them)."""
+        (SlicPlan.round(..., bbox=self.bbox) on the round that made them).
+        max_segment_px: an upper bound on the pixels of any segment that the caller can prove (a
+        SLIC superpixel lies inside its centre's 2S x 2S window, slic.py:94-100); when it is within
+        the on-chip capacity no segment can be left for the streaming rounds, so the count of
+        such segments is not read back and the call does not synchronise."""
         lab = as_batch(_dev(lab, torch.uint8, "lab"))
         if labels.dim() == 2:
             labels = labels.unsqueeze(0)
@@ -481,7 +488,10 @@ class DcdPlan(object):
             check(fn(_ptr(lab), _ptr(labels), *shape, 1 if use_hash else 0, cseed, _ptr(centres),
                      _ptr(self.assign), _ptr(self.state), _ptr(self.stats), _ptr(self.bbox),
                      _ptr(self.n_big), int(max_rounds), _stream()))
-            self.big_segments = int(self.n_big.item())
+            if max_segment_px is not None and int(max_segment_px) <= self.LDS_CAPACITY:
+                self.big_segments = 0
+            else:
+                self.big_segments = int(self.n_big.item())
         self.rounds_run = 0
         if self.big_segments == 0:
             return centres, self.assign

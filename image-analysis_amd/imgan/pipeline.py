@@ -3,8 +3,7 @@
     BGR -> Lab -> SLIC (slic.py) -> dominant colours per superpixel (mpeg7Descriptors.py:76-130)
         + whole-image colour layout / edge histogram / colour structure
 
-Everything runs in libimgan_hip.so on the current stream; no host round trip except the
-per-round "segments still running" counter of the dominant-colour loop.  The outputs are the
+Everything runs in libimgan_hip.so on the current stream, with no host round trip.  The outputs are the
 fixed-width descriptor rows that the multi-GPU layout all-gathers (imgan.shard)."""
 import ctypes
 
@@ -67,9 +66,11 @@ class FullPipeline(object):
         p = ops._ptr
 
         def go():
-            self.dcd.kmeans(self.lab, labels, self.centres, seed=self.seed,
-                            max_rounds=self.max_rounds, check_every=self.check_every,
-                            boxed=getattr(self, "boxed", False))
+            # a superpixel lies inside its centre's window: at most (2S)^2 pixels
+            self._timed("dcd_segments", timed, lambda: self.dcd.kmeans(
+                self.lab, labels, self.centres, seed=self.seed, max_rounds=self.max_rounds,
+                check_every=self.check_every, boxed=getattr(self, "boxed", False),
+                max_segment_px=(2 * self.slic.S) ** 2))
             self.dcd_rounds_run = self.dcd.rounds_run
             stats = self.dcd.statistics(self.lab, labels)
             check(lib.imgan_dcd_features(p(stats), p(self.centres), self.B, self.n, self.k,
@@ -93,6 +94,17 @@ class FullPipeline(object):
         torch.cuda.synchronize()
         return {k: sum(a.elapsed_time(b) for a, b in v) / len(v)
                 for k, v in self.stage_events.items()}
+
+    def descriptor_bytes_per_px(self):
+        """Algorithmic bytes per pixel of the CLD / EHD / CSD stage as this pipeline runs it
+        (SURVEY 8d): whole-image descriptors read the image only, 3 B/px each."""
+        return 9
+
+    def segments_at_round_cap(self):
+        """Segments of the last dominant-colour pass whose Lloyd loop was cut at dcd_max_rounds
+        (the reference's loop is unbounded, mpeg7Descriptors.py:85-107)."""
+        rounds, _ = self.dcd.rounds()
+        return int((rounds >= self.max_rounds).sum().item())
 
     def mean_lloyd_rounds(self):
         """Pixel-weighted mean number of Lloyd rounds of the last dominant-colour pass."""
