@@ -266,7 +266,7 @@ def run_config_mosaic(steps, warmup):
     from imgan.pipeline import FullPipeline
     B, H, W, K = 1, 16384, 16384, 50000
     bgr = synth_batch(B, H, W, K, 99, "cuda")
-    pipe = FullPipeline(B, H, W, K, colour_weight=15, num_iter=10, dominant=8)
+    pipe = FullPipeline(B, H, W, K, colour_weight=15, num_iter=10, dominant=8, per_region=True)
     for _ in range(warmup):
         pipe.step(bgr)
     torch.cuda.synchronize()
@@ -282,7 +282,7 @@ def run_config_mosaic(steps, warmup):
     prof = "profiles/r02_mosaic_kernel_summary.txt"
     path_bytes = 6 + 63 + pipe.descriptor_bytes_per_px() + dcd_bytes
     rec = {"config": "configs[4] (one GPU's share): %d x %dx%d BGR, K=%d (n=%d, S=%d), Lab + SLIC + "
-                     "CLD / EHD / CSD + dominant colours k=8 of every superpixel (%.1f Lloyd rounds per pixel)" %
+                     "CLD / EHD / CSD and dominant colours k=8 of every superpixel (%.1f Lloyd rounds per pixel)" %
                      (B, W, H, K, pipe.n, pipe.slic.S, t_bar),
            "value": round(npix * steps / dt / 1e6, 2), "unit": "megapixels/sec",
            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
@@ -293,7 +293,12 @@ def run_config_mosaic(steps, warmup):
                                           "compulsory HBM traffic is 8 B/px"),
            "roofline_kernels": [roofline_line("slic_assign_kernel", ms["slic_assign"], 7, npix, profile=prof,
                                               launches=9),
+                                roofline_line("region_desc_kernel (+cld_finalise)", ms["region_desc"], 21, npix,
+                                              profile=prof, bound="lds/valu",
+                                              note="CLD + EHD + CSD per superpixel in one pass, priced at "
+                                                   "SURVEY 8d's 3 x 7 B/px"),
                                 roofline_line("bgr2lab_kernel", ms["bgr2lab"], 6, npix, profile=prof)],
+           "regions_too_large_for_region_desc": int(pipe.region_desc.too_big.item()),
            "path": {"bytes_per_px": round(path_bytes, 1),
                     "achieved": round(path_bytes * npix * steps / dt / 1e9, 1), "unit": "GB/s",
                     "frac": round(path_bytes * npix * steps / dt / 1e9 / HBM_PEAK_GBS, 4)},

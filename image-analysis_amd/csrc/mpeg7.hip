@@ -163,9 +163,11 @@ __device__ int quant_ac(int i) {
 
 // one wave per (image, channel), one lane per grid cell / coefficient: averages -> YCbCr ->
 // 8x8 DCT -> zig-zag -> quantise.  Every sum runs over k in the order of the serial statement.
+// fill_empty: a grid block without pixels takes the mean of all blocks' pixels (the per-region
+// form: blocks of the bounding box that the region does not reach)
 __global__ __launch_bounds__(64) void cld_finalise_kernel(const unsigned long long* __restrict__ sums,
                                                           int B, int32_t* __restrict__ out,
-                                                          DctTable T) {
+                                                          DctTable T, int fill_empty) {
     __shared__ double s_t[64], blk[64], tmp[64];
     __shared__ int coef[64];
     const int t = blockIdx.x, lane = threadIdx.x;
@@ -176,11 +178,27 @@ __global__ __launch_bounds__(64) void cld_finalise_kernel(const unsigned long lo
     {
         const int k = lane;
         unsigned long long n = S[4 * k + 3];
+        unsigned long long s0 = S[4 * k], s1 = S[4 * k + 1], s2 = S[4 * k + 2];
+        if (fill_empty) {                              // totals over the 64 blocks, every lane
+            unsigned long long t0 = s0, t1 = s1, t2 = s2, tn = n;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                t0 += __shfl_xor(t0, off);
+                t1 += __shfl_xor(t1, off);
+                t2 += __shfl_xor(t2, off);
+                tn += __shfl_xor(tn, off);
+            }
+            if (tn == 0) {                             // a region without pixels (or left out): zeros
+                out[((size_t)b * 3 + ch) * 64 + lane] = 0;
+                return;
+            }
+            if (n == 0) s0 = t0, s1 = t1, s2 = t2, n = tn;
+        }
         double Bc = 0.0, Gc = 0.0, Rc = 0.0;
         if (n) {
-            Bc = (double)(S[4 * k] / n);
-            Gc = (double)(S[4 * k + 1] / n);
-            Rc = (double)(S[4 * k + 2] / n);
+            Bc = (double)(s0 / n);
+            Gc = (double)(s1 / n);
+            Rc = (double)(s2 / n);
         }
         double yy = (0.299 * Rc + 0.587 * Gc + 0.114 * Bc) / 256.0;
         double v;
@@ -403,6 +421,214 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) o[nbins] = nwx * nwy;
 }
 
+// ------------------------------------------------------------------------------ per region
+// CLD / EHD / CSD of every region of a label map in one pass over image + labels (7 B/px): one
+// workgroup per region stages the cells of the region's bounding box in LDS (grey level, HMMD
+// colour cell, membership bit), adds up the 8 x 8 grid sums on the way, then walks the edge blocks
+// and the colour-structure windows of the box on chip.  Definitions: oracle/mpeg7_std.py
+// "per region".  A box of more than RD_CAP cells is left to the caller (counted in too_big).
+constexpr int RD_THREADS = 512, RD_CAP = 24576, RD_WORDS = RD_CAP / 64;
+static_assert(RD_CAP < 32768, "the colour structure's sub-sampling factor must stay 1 on chip");
+
+__device__ __forceinline__ int ehd_block_size_dev(int H, int W) {
+    const double temp = sqrt((double)W * H / 1100.0);
+    const int bs = (int)(temp / 2) * 2;
+    return bs ? bs : 2;
+}
+
+// 64 bits of a bitmap over the box's cells, starting `shift` bits after the start of word w
+__device__ __forceinline__ unsigned long long bits_at(const unsigned long long* bm, int w, int shift,
+                                                      int nwords) {
+    const int ws = w + (shift >> 6), bs = shift & 63;
+    const unsigned long long lo = ws < nwords ? bm[ws] : 0ull;
+    const unsigned long long hi = ws + 1 < nwords ? bm[ws + 1] : 0ull;
+    return bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
+}
+
+__global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
+    const uint8_t* __restrict__ img, const int32_t* __restrict__ labels, const int32_t* __restrict__ bbox,
+    int H, int W, int nseg, int nbins, HmmdTab T, unsigned long long* __restrict__ cld_sums,
+    int32_t* __restrict__ ehd_out, int32_t* __restrict__ csd_out, int32_t* __restrict__ too_big) {
+    __shared__ uint8_t gray[RD_CAP], col[RD_CAP];
+    // bitmaps over the cells of the box, row-major with the box's own pitch: the region's cells,
+    // the cells where an 8 x 8 window fits, and per colour pass the cells of two colours (R) and
+    // their dilation along x (D)
+    __shared__ unsigned long long member[RD_WORDS], fits[RD_WORDS], R[2][RD_WORDS], D[2][RD_WORDS];
+    __shared__ uint32_t tab[64 * 4], hist[256], ehd[96], present[8];
+    __shared__ uint32_t nwin;
+    const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const size_t gs = (size_t)b * nseg + s;
+    const int* bb = bbox + gs * 4;
+    const int x0 = max(bb[0], 0), y0 = max(bb[1], 0), x1 = min(bb[2], W - 1), y1 = min(bb[3], H - 1);
+    unsigned long long* csum = cld_sums + gs * 64 * 4;
+    int32_t* eo = ehd_out + gs * 96;
+    int32_t* co = csd_out + gs * (size_t)(nbins + 1);
+    const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+    const bool empty = x1 < x0 || y1 < y0;
+    const long long area_ll = empty ? 0 : (long long)bw * bh;
+    if (empty || area_ll > RD_CAP) {                     // nothing, or too large for the chip
+        for (int i = tid; i < 64 * 4; i += RD_THREADS) csum[i] = 0ull;
+        for (int i = tid; i < 96; i += RD_THREADS) eo[i] = 0;
+        for (int i = tid; i <= nbins; i += RD_THREADS) co[i] = 0;
+        if (!empty && tid == 0) atomicAdd(too_big, 1);
+        return;
+    }
+    const int area = (int)area_ll, nwords = (area + 63) >> 6;
+    for (int i = tid; i < 64 * 4; i += RD_THREADS) tab[i] = 0;
+    for (int i = tid; i < 256; i += RD_THREADS) hist[i] = 0;
+    for (int i = tid; i < 96; i += RD_THREADS) ehd[i] = 0;
+    if (tid < 8) present[tid] = 0;
+    if (tid == 0) nwin = 0;
+    __syncthreads();
+
+    // ---- stage the box; 8 x 8 grid sums of the region's pixels on the way
+    const uint8_t* im = img + (size_t)b * H * W * 3;
+    const int32_t* lab = labels + (size_t)b * H * W;
+    const float inv_bw = 1.0f / (float)bw;
+    for (int i0 = 0; i0 < area; i0 += RD_THREADS) {
+        const int i = i0 + tid;
+        bool mem = false, fit = false;
+        if (i < area) {
+            int yy = (int)((float)i * inv_bw);
+            int xx = i - yy * bw;
+            yy += (xx >= bw) - (xx < 0);                 // the float quotient can be off by one
+            xx = i - yy * bw;
+            fit = xx + 8 <= bw && yy + 8 <= bh;
+            const size_t p = (size_t)(y0 + yy) * W + (x0 + xx);
+            mem = lab[p] == s;
+            const uint8_t* q = im + p * 3;
+            const uint32_t cb = q[0], cg = q[1], cr = q[2];
+            gray[i] = (uint8_t)gray_px(cb, cg, cr);
+            if (mem) {
+                const uint32_t c = (uint32_t)hmmd_cell((int)cb, (int)cg, (int)cr, T);
+                col[i] = (uint8_t)c;
+                if (!((present[c >> 5] >> (c & 31u)) & 1u)) atomicOr(&present[c >> 5], 1u << (c & 31u));
+                const int blk = ((yy * 8) / bh) * 8 + (xx * 8) / bw;
+                atomicAdd(&tab[blk * 4], cb);
+                atomicAdd(&tab[blk * 4 + 1], cg);
+                atomicAdd(&tab[blk * 4 + 2], cr);
+                atomicAdd(&tab[blk * 4 + 3], 1u);
+            }
+        }
+        const unsigned long long mbits = __ballot(mem), fbits = __ballot(fit);   // 64 consecutive cells
+        if (lane == 0 && i < area) member[i >> 6] = mbits, fits[i >> 6] = fbits;
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 4; i += RD_THREADS) csum[i] = tab[i];
+    auto is_member = [&](int cell) { return (member[cell >> 6] >> (cell & 63)) & 1ull; };
+
+    // ---- edge histogram: blocks tile the box from its corner; a block votes if the region holds
+    // all of its pixels
+    {
+        const int bs = ehd_block_size_dev(bh, bw), hb = bs >> 1;
+        const int nbx = bw / bs, nby = bh / bs;
+        for (int k = tid; k < nbx * nby; k += RD_THREADS) {
+            const int by = k / nbx, bx = k - by * nbx;
+            long long s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+            bool all = true;
+            for (int j = 0; j < bs; ++j)
+                for (int i = 0; i < bs; ++i) {
+                    const int cell = (by * bs + j) * bw + bx * bs + i;
+                    all = all && is_member(cell);
+                    const long long g = gray[cell];
+                    s1 += (j < hb && i < hb) ? g : 0;
+                    s2 += (j < hb && i >= hb) ? g : 0;
+                    s3 += (j >= hb && i < hb) ? g : 0;
+                    s4 += (j >= hb && i >= hb) ? g : 0;
+                }
+            if (!all) continue;
+            const long long v = s1 - s2 + s3 - s4, h = s1 + s2 - s3 - s4, d45 = s1 - s4, d135 = s2 - s3,
+                            nd = s1 - s2 - s3 + s4;
+            const long long e[5] = {v * v, h * h, 2 * d45 * d45, 2 * d135 * d135, 4 * nd * nd};
+            long long best = e[0];
+            int type = 0;
+#pragma unroll
+            for (int t = 1; t < 5; ++t)
+                if (e[t] > best) best = e[t], type = t;
+            const int sub = (bx * bs * 4) / bw + ((by * bs * 4) / bh) * 4;
+            atomicAdd(&ehd[80 + sub], 1u);
+            const long long thr = 11ll * hb * hb;
+            if (best >= thr * thr) atomicAdd(&ehd[sub * 5 + type], 1u);
+        }
+    }
+
+    // ---- colour structure.  A window (origin u, v) holds colour c iff one of the region's cells
+    // in [u, u+8) x [v, v+8) has it: the windows of c are the 8 x 8 dilation of c's cells towards
+    // the origin.  On bitmaps over the box's cells that is seven shifts by one bit (x) and seven
+    // by one row pitch (y); bits that a shift carries across a row end land on origins where no
+    // window fits, which the `fits` bitmap removes before the count.  Two colours per pass; the
+    // last pass takes the region's own bitmap for the number of windows that hold a region pixel.
+    if (bw >= 8 && bh >= 8) {
+        int w8 = 0;
+        uint32_t bits = present[0];
+        auto next_colour = [&]() -> int {               // ascending; -2 when none is left
+            while (bits == 0u && w8 < 7) bits = present[++w8];
+            if (bits == 0u) return -2;
+            const int bit = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            return w8 * 32 + bit;
+        };
+        bool last = false;
+        while (!last) {
+            // two colours per pass; -1 = the membership pass (the last one); -2 = nothing
+            int c0 = next_colour(), c1 = -2;
+            if (c0 == -2) {
+                c0 = -1;
+                last = true;
+            } else {
+                c1 = next_colour();
+                if (c1 == -2) {
+                    c1 = -1;
+                    last = true;
+                }
+            }
+            for (int i0 = 0; i0 < area; i0 += RD_THREADS) {
+                const int i = i0 + tid;
+                bool b0 = false, b1 = false;
+                if (i < area && is_member(i)) {
+                    const int c = col[i];
+                    b0 = c0 == -1 || c == c0;
+                    b1 = c1 == -1 || c == c1;
+                }
+                const unsigned long long r0 = __ballot(b0), r1 = __ballot(b1);
+                if (lane == 0 && i < area) R[0][i >> 6] = r0, R[1][i >> 6] = r1;
+            }
+            __syncthreads();
+            for (int k = tid; k < 2 * nwords; k += RD_THREADS) {
+                const int which = k >= nwords, w = k - which * nwords;
+                const unsigned long long p = R[which][w], n = w + 1 < nwords ? R[which][w + 1] : 0ull;
+                unsigned long long d = p;
+#pragma unroll
+                for (int dx = 1; dx < 8; ++dx) d |= (p >> dx) | (n << (64 - dx));
+                D[which][w] = d;
+            }
+            __syncthreads();
+            uint32_t cnt0 = 0, cnt1 = 0;
+            for (int k = tid; k < 2 * nwords; k += RD_THREADS) {
+                const int which = k >= nwords, w = k - which * nwords;
+                unsigned long long v = D[which][w];
+#pragma unroll
+                for (int dy = 1; dy < 8; ++dy) v |= bits_at(D[which], w, dy * bw, nwords);
+                const uint32_t c = (uint32_t)__popcll(v & fits[w]);
+                if (which) cnt1 += c;
+                else cnt0 += c;
+            }
+            cnt0 = wave_sum(cnt0);
+            cnt1 = wave_sum(cnt1);
+            if (lane == 0) {
+                if (cnt0) atomicAdd(c0 == -1 ? &nwin : &hist[c0], cnt0);
+                if (cnt1 && c1 != -2) atomicAdd(c1 == -1 ? &nwin : &hist[c1], cnt1);
+            }
+            // R is rewritten only after every thread has passed the barrier behind the D phase;
+            // D only after the next pass's first barrier
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 96; i += RD_THREADS) eo[i] = (int32_t)ehd[i];
+    for (int i = tid; i < nbins; i += RD_THREADS) co[i] = (int32_t)hist[i];
+    if (tid == 0) co[nbins] = (int32_t)nwin;
+}
+
 int make_hmmd(int nbins, HmmdTab* T) {
     static const int thr5[6] = {0, 6, 20, 60, 110, 256};
     static const int thr4[5] = {0, 6, 60, 110, 256};
@@ -450,7 +676,7 @@ static int cld_run(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out,
         for (int j = 0; j < 8; ++j) T.c[i * 8 + j] = s * cos((M_PI / 8.0) * i * (j + 0.5));
     }
     hipLaunchKernelGGL(cld_finalise_kernel, dim3(B * 3), dim3(64), 0, st,
-                       (const unsigned long long*)sums, B, cld_out, T);
+                       (const unsigned long long*)sums, B, cld_out, T, 0);
     return imgan::check_launch(what);
 }
 
@@ -573,4 +799,34 @@ extern "C" int imgan_csd(const uint8_t* bgr, int B, int H, int W, int nbins, int
     dim3 grid((unsigned)imgan::cdiv(nwx, CS_W), (unsigned)imgan::cdiv(nwy, CS_H), (unsigned)B);
     hipLaunchKernelGGL(csd_kernel, grid, dim3(256), 0, st, bgr, H, W, K, nwx, nwy, nbins, csd_out, T);
     return imgan::check_launch("imgan_csd");
+}
+
+extern "C" size_t imgan_region_descriptors_scratch_bytes(int B, int nseg) {
+    return B < 1 || nseg < 1 ? 0 : (size_t)B * nseg * 64 * 4 * 8;
+}
+
+extern "C" int imgan_region_descriptors(const uint8_t* bgr, const int32_t* labels, const int32_t* bbox,
+                                        int B, int H, int W, int nseg, int nbins, int32_t* cld_out,
+                                        int32_t* ehd_out, int32_t* csd_out, int32_t* too_big_out,
+                                        void* scratch, imgan_stream_t stream) {
+    IMGAN_REQUIRE(bgr && labels && bbox && cld_out && ehd_out && csd_out && too_big_out && scratch,
+                  "imgan_region_descriptors: null pointer");
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535,
+                  "imgan_region_descriptors: bad shape");
+    IMGAN_REQUIRE((long long)B * nseg * 3 < 0x7fffffffLL, "imgan_region_descriptors: too many regions");
+    HmmdTab T;
+    if (int rc = make_hmmd(nbins, &T)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    IMGAN_HIP(hipMemsetAsync(too_big_out, 0, 4, st));
+    hipLaunchKernelGGL(region_desc_kernel, dim3((unsigned)nseg, (unsigned)B), dim3(RD_THREADS), 0, st, bgr,
+                       labels, bbox, H, W, nseg, nbins, T, (unsigned long long*)scratch, ehd_out, csd_out,
+                       too_big_out);
+    DctTable D;
+    for (int i = 0; i < 8; ++i) {
+        double s = i == 0 ? sqrt(0.125) : 0.5;
+        for (int j = 0; j < 8; ++j) D.c[i * 8 + j] = s * cos((M_PI / 8.0) * i * (j + 0.5));
+    }
+    hipLaunchKernelGGL(cld_finalise_kernel, dim3(B * nseg * 3), dim3(64), 0, st,
+                       (const unsigned long long*)scratch, B * nseg, cld_out, D, 1);
+    return imgan::check_launch("imgan_region_descriptors");
 }

@@ -578,6 +578,55 @@ class DescriptorPlan(object):
         return self.csd
 
 
+def label_bbox(labels, nseg):
+    """int32 [B,nseg,4] = xmin, ymin, xmax, ymax of every label (xmax = -1: no pixels)."""
+    _require_gpu()
+    if labels.dim() == 2:
+        labels = labels.unsqueeze(0)
+    _dev(labels, torch.int32, "labels")
+    B, H, W = labels.shape
+    bbox = torch.empty((B, int(nseg), 4), dtype=torch.int32, device=labels.device)
+    check(lib.imgan_label_bbox(_ptr(labels), B, H, W, int(nseg), _ptr(bbox), _stream()))
+    return bbox
+
+
+class RegionDescriptorPlan(object):
+    """Colour layout, edge histogram and colour structure of every region of a label map (one
+    workgroup per region, bounding box staged in LDS; imgan_region_descriptors)."""
+
+    MAX_BOX_CELLS = 24576
+
+    def __init__(self, B, H, W, nseg, nbins=256):
+        _require_gpu()
+        self.B, self.H, self.W, self.nseg, self.nbins = int(B), int(H), int(W), int(nseg), int(nbins)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.cld = torch.empty((self.B, self.nseg, 3, 64), dtype=torch.int32, device=dev)
+        self.ehd = torch.empty((self.B, self.nseg, 96), dtype=torch.int32, device=dev)
+        self.csd = torch.empty((self.B, self.nseg, self.nbins + 1), dtype=torch.int32, device=dev)
+        self.too_big = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scratch = torch.empty(max(lib.imgan_region_descriptors_scratch_bytes(self.B, self.nseg), 8),
+                                   dtype=torch.uint8, device=dev)
+
+    def run(self, bgr, labels, bbox=None):
+        """bbox: device buffer holding int32 [B,nseg,4] (e.g. the one the last SLIC round wrote);
+        found with imgan_label_bbox when not given.  Returns (cld, ehd, csd) device tensors."""
+        bgr = as_batch(_dev(bgr, torch.uint8, "bgr"))
+        if labels.dim() == 2:
+            labels = labels.unsqueeze(0)
+        _dev(labels, torch.int32, "labels")
+        if tuple(bgr.shape) != (self.B, self.H, self.W, 3) or tuple(labels.shape) != (self.B, self.H, self.W):
+            raise ValueError("batch does not match the plan")
+        if bbox is None:
+            bbox = label_bbox(labels, self.nseg)
+        elif bbox.numel() * bbox.element_size() < self.B * self.nseg * 16:
+            raise ValueError("bbox buffer too small")
+        check(lib.imgan_region_descriptors(_ptr(bgr), _ptr(labels), _ptr(bbox), self.B, self.H, self.W,
+                                           self.nseg, self.nbins, _ptr(self.cld), _ptr(self.ehd),
+                                           _ptr(self.csd), _ptr(self.too_big), _ptr(self.scratch),
+                                           _stream()))
+        return self.cld, self.ehd, self.csd
+
+
 def hmmd_quantise(bgr, nbins=256):
     _require_gpu()
     _dev(bgr, torch.uint8, "bgr")

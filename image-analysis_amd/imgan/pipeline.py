@@ -15,7 +15,10 @@ from ._lib import lib, check
 
 class FullPipeline(object):
     def __init__(self, B, H, W, num_clusters, colour_weight=15, num_iter=10, dominant=8,
-                 csd_bins=256, dcd_seed=12345, dcd_check_every=4, dcd_max_rounds=200):
+                 csd_bins=256, dcd_seed=12345, dcd_check_every=4, dcd_max_rounds=200,
+                 per_region=False):
+        """per_region: colour layout / edge histogram / colour structure of every superpixel
+        (configs[4]) instead of the whole image."""
         self.B, self.H, self.W = int(B), int(H), int(W)
         self.cw, self.num_iter, self.k = colour_weight, int(num_iter), int(dominant)
         self.seed, self.check_every, self.max_rounds = dcd_seed, dcd_check_every, dcd_max_rounds
@@ -23,7 +26,9 @@ class FullPipeline(object):
         self.n = self.slic.n
         dev = self.slic.device
         self.lab = torch.empty((self.B, self.H, self.W, 3), dtype=torch.uint8, device=dev)
-        self.desc = ops.DescriptorPlan(B, H, W, csd_bins)
+        self.per_region = bool(per_region)
+        self.desc = ops.DescriptorPlan(B, H, W, csd_bins) if not per_region else None
+        self.region_desc = ops.RegionDescriptorPlan(B, H, W, self.slic.n, csd_bins) if per_region else None
         self.dcd = ops.DcdPlan(B, H, W, self.n, self.k)
         self.centres = torch.empty((self.B, self.n, self.k, 3), dtype=torch.float32, device=dev)
         self.features = torch.empty((self.B, self.n, self.k, 8), dtype=torch.float32, device=dev)
@@ -82,6 +87,13 @@ class FullPipeline(object):
         """One pass of the whole path over the resident batch.
         Returns (image_rows int32 [B, 12+80+16+csd_bins+1], region_rows float32 [B, n*k*8])."""
         self.run_slic(bgr, timed)
+        if self.per_region:
+            # rows per superpixel [B, n, 12+96+csd_bins+1]; the boxes are the last SLIC round's
+            cld, ehd, csd = self._timed("region_desc", timed, lambda: self.region_desc.run(
+                bgr, self.slic.labels, bbox=self.dcd.bbox if self.boxed else None))
+            feats = self.run_dcd(timed)
+            rows = torch.cat([cld[:, :, 0, :6], cld[:, :, 1, :3], cld[:, :, 2, :3], ehd, csd], dim=2)
+            return rows.view(self.B, -1), feats.view(self.B, -1)
         cld = self._timed("cld", timed, lambda: self.desc.colour_layout(bgr))
         ehd = self._timed("ehd", timed, lambda: self.desc.edge_histogram(bgr))
         csd = self._timed("csd", timed, lambda: self.desc.colour_structure(bgr))
@@ -97,8 +109,9 @@ class FullPipeline(object):
 
     def descriptor_bytes_per_px(self):
         """Algorithmic bytes per pixel of the CLD / EHD / CSD stage as this pipeline runs it
-        (SURVEY 8d): whole-image descriptors read the image only, 3 B/px each."""
-        return 9
+        (SURVEY 8d): whole-image descriptors read the image only, 3 B/px each; the per-region
+        form reads image + labels, 7 B/px each (one fused pass here, priced as the survey does)."""
+        return 21 if self.per_region else 9
 
     def segments_at_round_cap(self):
         """Segments of the last dominant-colour pass whose Lloyd loop was cut at dcd_max_rounds

@@ -270,6 +270,22 @@ int imgan_csd(const uint8_t* bgr, int B, int H, int W, int nbins, int32_t* csd_o
 int imgan_hmmd_quantise(const uint8_t* bgr, uint8_t* out, int64_t npix, int nbins,
                         imgan_stream_t stream);
 
+/* The same three descriptors for every region of a label map (ids 0..nseg-1), one pass over image
+ * and labels (BASELINE.json configs[4]: descriptors per superpixel region; not in the reference,
+ * defined in oracle/mpeg7_std.py "per region": everything relative to the region's bounding box,
+ * only the region's pixels count, empty colour-layout blocks take the region's mean).
+ * bbox: int32 [B][nseg][4] = xmin, ymin, xmax, ymax as imgan_label_bbox or
+ * imgan_slic_assign_accumulate_bbox leave them.  cld_out int32 [B][nseg][3][64], ehd_out int32
+ * [B][nseg][96], csd_out int32 [B][nseg][nbins+1].  A region whose box has more than 24,576 cells
+ * does not fit on chip: its rows are zeroed and it is counted in too_big_out (device int32); such
+ * regions (merged regions, whole frames) take the whole-image entry points on their crop.
+ * scratch: imgan_region_descriptors_scratch_bytes(B, nseg) bytes. */
+size_t imgan_region_descriptors_scratch_bytes(int B, int nseg);
+int imgan_region_descriptors(const uint8_t* bgr, const int32_t* labels, const int32_t* bbox, int B,
+                             int H, int W, int nseg, int nbins, int32_t* cld_out, int32_t* ehd_out,
+                             int32_t* csd_out, int32_t* too_big_out, void* scratch,
+                             imgan_stream_t stream);
+
 /* ---- spatial relations (spatialextract.py) ------------------------------------
  * imgan_label_bbox: bounding box of every label (cv2.boundingRect of the segment mask,
  * spatialextract.py:9-11,47).  bbox: int32 [B][nseg][4] = xmin, ymin, xmax, ymax

@@ -314,3 +314,101 @@ def csd_quantise(hist, nwin):
             base += CSD_AMP_LEVELS[r]
         out[i] = min(val, 255)
     return out
+
+
+# ----------------------------------------------------------------------------- per region
+# The same three descriptors for one region of a label map (BASELINE.json configs[4]:
+# "descriptors per superpixel region"; SURVEY.md 8d prices them at 3 + 4 B/px: image + labels).
+# Own definition, after the standard's treatment of arbitrarily shaped regions; parity unpinned.
+# Everything is taken relative to the region's bounding box (x0, y0, bw, bh):
+#   CLD: the 8 x 8 grid spans the box; a block's mean runs over the region's pixels in it; a block
+#        without such pixels takes the region's mean colour (integer floor, as the block means)
+#   EHD: image blocks tile the box from its corner, size from the box's area; a block votes only
+#        if all of its pixels belong to the region
+#   CSD: the structuring element slides over the box (sub-sampling from the box's area); only the
+#        region's pixels put their colour into a window; windows that hold none are not counted
+
+def region_bbox(labels, r):
+    ys, xs = np.nonzero(labels == r)
+    if ys.size == 0:
+        return None
+    return int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)
+
+
+def region_cld_block_sums(img, labels, r):
+    x0, y0, bw, bh = region_bbox(labels, r)
+    crop = img[y0:y0 + bh, x0:x0 + bw].astype(np.int64)
+    m = labels[y0:y0 + bh, x0:x0 + bw] == r
+    gx = (np.arange(bw) * 8) // bw
+    gy = (np.arange(bh) * 8) // bh
+    blk = (gy[:, None] * 8 + gx[None, :])[m]
+    cnt = np.bincount(blk, minlength=64).astype(np.int64)
+    sums = np.stack([np.bincount(blk, weights=crop[..., k][m], minlength=64).astype(np.int64)
+                     for k in range(3)], axis=1)
+    return sums, cnt
+
+
+def region_colour_layout_full(img, labels, r):
+    """int32 [3, 64]; empty blocks take floor(region sum / region count)."""
+    sums, cnt = region_cld_block_sums(img, labels, r)
+    tot, n = sums.sum(axis=0), int(cnt.sum())
+    fill = np.array([int(t) // n for t in tot], dtype=np.int64)
+    sums2, cnt2 = sums.copy(), cnt.copy()
+    for k in range(64):
+        if cnt[k] == 0:
+            sums2[k], cnt2[k] = fill, 1
+    return cld_from_sums(sums2, cnt2)
+
+
+def region_edge_histogram_counts(img, labels, r, threshold=11):
+    x0, y0, bw, bh = region_bbox(labels, r)
+    gray = bgr2gray_u8(img[y0:y0 + bh, x0:x0 + bw]).astype(np.int64)
+    m = labels[y0:y0 + bh, x0:x0 + bw] == r
+    bs = ehd_block_size(bh, bw)
+    hb = bs // 2
+    q = hb * hb
+    counts = np.zeros(80, dtype=np.int32)
+    nblk = np.zeros(16, dtype=np.int32)
+    for j in range(0, bh - bs + 1, bs):
+        for i in range(0, bw - bs + 1, bs):
+            if not m[j:j + bs, i:i + bs].all():
+                continue
+            sub = (i * 4) // bw + ((j * 4) // bh) * 4
+            nblk[sub] += 1
+            s1 = int(gray[j:j + hb, i:i + hb].sum())
+            s2 = int(gray[j:j + hb, i + hb:i + bs].sum())
+            s3 = int(gray[j + hb:j + bs, i:i + hb].sum())
+            s4 = int(gray[j + hb:j + bs, i + hb:i + bs].sum())
+            sq = [(s1 - s2 + s3 - s4) ** 2, (s1 + s2 - s3 - s4) ** 2,
+                  2 * (s1 - s4) ** 2, 2 * (s2 - s3) ** 2, 4 * (s1 - s2 - s3 + s4) ** 2]
+            best, e = sq[0], 0
+            for t in range(1, 5):
+                if sq[t] > best:
+                    best, e = sq[t], t
+            if best >= (threshold * q) ** 2:
+                counts[sub * 5 + e] += 1
+    return counts, nblk
+
+
+def region_colour_structure_counts(img, labels, r, nbins=256):
+    x0, y0, bw, bh = region_bbox(labels, r)
+    K = csd_subsample(bh, bw)
+    nwx = (bw - 8 * K) // K + 1 if bw >= 8 * K else 0
+    nwy = (bh - 8 * K) // K + 1 if bh >= 8 * K else 0
+    hist = np.zeros(nbins, dtype=np.int32)
+    if nwx <= 0 or nwy <= 0:
+        return hist, 0
+    crop = img[y0:y0 + bh, x0:x0 + bw][0:(nwy + 7) * K:K, 0:(nwx + 7) * K:K]
+    m = (labels[y0:y0 + bh, x0:x0 + bw] == r)[0:(nwy + 7) * K:K, 0:(nwx + 7) * K:K]
+    qimg = hmmd_quantise(crop, nbins).astype(np.int64)
+    qimg[~m] = -1
+    anyin = np.zeros((nwy, nwx), dtype=bool)
+    for c in np.unique(qimg[qimg >= 0]):
+        mc = qimg == c
+        acc = np.zeros((nwy, nwx), dtype=bool)
+        for dy in range(8):
+            for dx in range(8):
+                acc |= mc[dy:dy + nwy, dx:dx + nwx]
+        hist[int(c)] = int(acc.sum())
+        anyin |= acc
+    return hist, int(anyin.sum())

@@ -305,3 +305,72 @@ def test_dcd_lds_path_equals_streaming_path(k):
     assert np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][2], out[1][2])
     assert np.array_equal(out[0][3], out[1][3])
+
+
+def _region_oracle_rows(img, labels, r):
+    from oracle import mpeg7_std as M
+    cld = M.region_colour_layout_full(img, labels, r)
+    counts, nblk = M.region_edge_histogram_counts(img, labels, r)
+    hist, nwin = M.region_colour_structure_counts(img, labels, r)
+    return cld, np.concatenate([counts, nblk]), np.concatenate([hist, [nwin]])
+
+
+def test_region_descriptors_match_oracle_on_superpixels():
+    """Per-region colour layout / edge histogram / colour structure of every SLIC superpixel of two
+    images (boxes handed over by the last SLIC round) against oracle.mpeg7_std's per-region forms."""
+    torch = _torch()
+    from imgan.pipeline import FullPipeline
+    H, W, K = 150, 230, 24
+    imgs = np.stack([voronoi_image(H, W, 9, seed=s, noise=12.0) for s in (71, 72)])
+    pipe = FullPipeline(2, H, W, K, dominant=4, per_region=True)
+    rows, _ = pipe.step(torch.from_numpy(imgs).cuda())
+    labels = pipe.slic.labels.cpu().numpy()
+    cld = pipe.region_desc.cld.cpu().numpy()
+    ehd = pipe.region_desc.ehd.cpu().numpy()
+    csd = pipe.region_desc.csd.cpu().numpy()
+    assert int(pipe.region_desc.too_big.item()) == 0
+    assert rows.shape == (2, pipe.n * (12 + 96 + 257))
+    checked = 0
+    for b in range(2):
+        for r in range(pipe.n):
+            if not (labels[b] == r).any():
+                assert not cld[b, r].any() and not ehd[b, r].any() and not csd[b, r].any()
+                continue
+            wc, we, ws = _region_oracle_rows(imgs[b], labels[b], r)
+            assert np.array_equal(cld[b, r], wc), (b, r)
+            assert np.array_equal(ehd[b, r], we), (b, r)
+            assert np.array_equal(csd[b, r], ws), (b, r)
+            checked += 1
+    assert checked >= 2 * pipe.n - 4
+
+
+def test_region_descriptors_odd_shapes_and_limits():
+    """Hand-made label maps: a ring (empty colour-layout blocks inside its box), thin and tiny
+    regions (no window fits), a region reaching the image corner, an id without pixels, and a
+    region too large for the chip (counted, rows zero)."""
+    torch = _torch()
+    from imgan import ops
+    H, W = 200, 260
+    img = voronoi_image(H, W, 30, seed=5, noise=20.0)
+    labels = np.full((H, W), -1, dtype=np.int32)
+    labels[:, :] = 6                                            # background region: box = whole frame
+    yy, xx = np.mgrid[0:H, 0:W]
+    d = np.hypot(yy - 60, xx - 70)
+    labels[(d < 40) & (d >= 25)] = 0                            # ring
+    labels[120:123, 10:150] = 1                                 # thin strip
+    labels[150:155, 200:205] = 2                                # 5 x 5
+    labels[H - 40:, W - 50:] = 3                                # touches the corner
+    labels[10:12, 200:202] = 5                                  # 2 x 2 (id 4 has no pixels)
+    nseg = 7
+    plan = ops.RegionDescriptorPlan(1, H, W, nseg)
+    dev = torch.from_numpy(img).cuda().unsqueeze(0)
+    cld, ehd, csd = plan.run(dev, torch.from_numpy(labels).cuda().unsqueeze(0))
+    cld, ehd, csd = cld.cpu().numpy()[0], ehd.cpu().numpy()[0], csd.cpu().numpy()[0]
+    assert int(plan.too_big.item()) == 1                        # region 6: 52,000 cells
+    assert not cld[6].any() and not csd[6].any() and not cld[4].any()
+    for r in (0, 1, 2, 3, 5):
+        wc, we, ws = _region_oracle_rows(img, labels, r)
+        assert np.array_equal(cld[r], wc), r
+        assert np.array_equal(ehd[r], we), r
+        assert np.array_equal(csd[r], ws), r
+    assert csd[0, 256] > 0 and csd[1, 256] == 0 and ehd[3, 80:].sum() > 0
