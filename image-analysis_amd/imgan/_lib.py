@@ -25,6 +25,7 @@ SIGNATURES = {
     "imgan_bgr2gray_u8": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "imgan_median7_u8c3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "imgan_median_u8c3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "imgan_resize_linear_u8c3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "imgan_slic_grid_host": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_slic_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "imgan_slic_init": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
@@ -55,6 +56,9 @@ SIGNATURES = {
     "imgan_relabel_lut": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p]),
     "imgan_paint_means": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p]),
     "imgan_cc_label": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "imgan_enforce_connectivity_scratch_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "imgan_enforce_connectivity": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                           c_void_p]),
     "imgan_dcd_state_bytes": (c_size_t, [c_int, c_int, c_int]),
     "imgan_dcd_kmeans_round": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

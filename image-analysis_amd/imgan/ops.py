@@ -85,6 +85,22 @@ def median7(bgr, out=None):
     return median_blur(bgr, 7, out)
 
 
+def resize_linear(bgr, dsize, out=None):
+    """cv2.resize(bgr, dsize) with the default INTER_LINEAR (optigen_utils.py:23); dsize is
+    (width, height) as in OpenCV."""
+    _require_gpu()
+    img = as_batch(_dev(bgr, torch.uint8, "bgr"))
+    B, Hs, Ws, _ = img.shape
+    Wd, Hd = int(dsize[0]), int(dsize[1])
+    if Wd < 1 or Hd < 1:
+        raise ValueError("resize: empty destination size")
+    if out is None:
+        out = torch.empty((B, Hd, Wd, 3) if bgr.dim() == 4 else (Hd, Wd, 3), dtype=torch.uint8,
+                          device=bgr.device)
+    check(lib.imgan_resize_linear_u8c3(_ptr(img), _ptr(out), B, Hs, Ws, Hd, Wd, _stream()))
+    return out
+
+
 def slic_grid(H, W, num_clusters, step=None):
     """(step, nx, ny) exactly as slic.py:29-33,42-43 derive them."""
     s, nx, ny = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -386,46 +402,30 @@ def cc_label(values):
     return roots
 
 
-def enforce_connectivity(labels):
+def enforce_connectivity(labels, nlabels=None):
     """Connectivity enforcement for a superpixel label map (named by the task; scripts/slic.py has
     no such step, so the rule is this package's own and additive: SLICSuperPixel never applies it
     unless asked).  Components = 8-connected sets of equal labels, found by the label-propagation
-    union-find kernel (imgan_cc_label).  For every label its largest component stays (ties: the
-    one that starts first in raster order); every other component takes the label of the pixel
-    left of its first raster pixel (above it in column 0), as read from the input map; a
-    component with no labelled pixel there keeps its label.  One pass; unlabelled pixels (-1)
-    stay unlabelled.  labels: int32 [B,H,W] or [H,W] device tensor; returns a new tensor."""
+    union-find kernel.  For every label its largest component stays (ties: the one that starts
+    first in raster order); every other component takes the label of the pixel left of its first
+    raster pixel (above it in column 0), as read from the input map; a component with no labelled
+    pixel there keeps its label.  One pass; unlabelled pixels (-1) stay unlabelled.  All of it
+    runs in imgan_enforce_connectivity.  labels: int32 [B,H,W] or [H,W] device tensor; nlabels: an
+    upper bound on the label values + 1 (read from the map, with one synchronisation, when not
+    given).  Returns a new tensor."""
     _require_gpu()
     squeeze = labels.dim() == 2
     if squeeze:
         labels = labels.unsqueeze(0)
     _dev(labels, torch.int32, "labels")
     B, H, W = labels.shape
-    roots = cc_label(labels)
-    out = labels.clone()
-    for b in range(B):                       # the bookkeeping below is per image and tiny next to the kernel
-        lab = labels[b].reshape(-1).long()
-        rt = roots[b].reshape(-1).long()
-        valid = rt >= 0
-        if not bool(valid.any()):
-            continue
-        comp, size = torch.unique(rt[valid], return_counts=True)      # component = its first raster pixel
-        clab = lab[comp]
-        # per label: the largest component, the earliest one among equals
-        order = torch.argsort(comp, stable=True)
-        order = order[torch.argsort(-size[order], stable=True)]
-        order = order[torch.argsort(clab[order], stable=True)]
-        first = torch.ones_like(order, dtype=torch.bool)
-        first[1:] = clab[order][1:] != clab[order][:-1]
-        keep = torch.zeros_like(first)
-        keep[order] = first
-        x0 = comp % W
-        nb = torch.where(x0 > 0, comp - 1, comp - W)                  # left neighbour, else the one above
-        nlab = torch.where(nb >= 0, lab[nb.clamp(min=0)], torch.full_like(nb, -1))
-        new = torch.where(keep | (nlab < 0), clab, nlab)
-        lut = torch.full((H * W,), -1, dtype=torch.long, device=labels.device)
-        lut[comp] = new
-        out[b] = torch.where(valid, lut[rt.clamp(min=0)], lab).view(H, W).int()
+    if nlabels is None:
+        nlabels = max(int(labels.max().item()) + 1, 1)
+    out = torch.empty_like(labels)
+    scratch = torch.empty(lib.imgan_enforce_connectivity_scratch_bytes(B, H, W, int(nlabels)),
+                          dtype=torch.uint8, device=labels.device)
+    check(lib.imgan_enforce_connectivity(_ptr(labels), _ptr(out), B, H, W, int(nlabels), _ptr(scratch),
+                                         _stream()))
     return out[0] if squeeze else out
 
 

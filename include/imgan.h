@@ -55,6 +55,12 @@ int imgan_median7_u8c3(const uint8_t* src, uint8_t* dst, int B, int H, int W,
 int imgan_median_u8c3(const uint8_t* src, uint8_t* dst, int B, int H, int W, int ksize,
                       imgan_stream_t stream);
 
+/* Replaces cv2.resize(img, (Wd, Hd)) (default INTER_LINEAR, 8 bit) at optigen_utils.py:23 and
+ * basegen.py:30: OpenCV's fixed-point bilinear filter with 11-bit weights; an exact 2 x 2
+ * reduction goes to the INTER_AREA rule as in OpenCV.  src [B][Hs][Ws][3], dst [B][Hd][Wd][3]. */
+int imgan_resize_linear_u8c3(const uint8_t* src, uint8_t* dst, int B, int Hs, int Ws, int Hd, int Wd,
+                             imgan_stream_t stream);
+
 /* ---- SLIC ------------------------------------------------------------------
  * imgan_slic_grid: slic.py:29,33 (step) and :42-43 (seed grid); host only.
  * step_in <= 0 selects the default int(sqrt(H*W / K)). */
@@ -178,6 +184,18 @@ int imgan_paint_means(uint8_t* img, const int32_t* labels, const uint8_t* means_
  * the component (image relative), -1 for background. */
 int imgan_cc_label(const int32_t* values, int32_t* roots, int B, int H, int W,
                    imgan_stream_t stream);
+
+/* Connectivity enforcement of a superpixel label map.  No counterpart in scripts/slic.py (it ends
+ * after the centre update, :78-127); named by the task, so the rule is this library's own and
+ * nothing applies it unless asked: components = 8-connected sets of equal labels; per label the
+ * largest component stays (ties: the one whose first raster pixel comes first); every other
+ * component takes the label of the pixel left of its first raster pixel (above it in column 0)
+ * as read from the input map, or keeps its label when that pixel is unlabelled or missing.  One
+ * pass; pixels < 0 stay as they are; labels >= nlabels are never relabelled.  labels / out: int32
+ * [B][H][W] (different buffers); scratch: imgan_enforce_connectivity_scratch_bytes() bytes. */
+size_t imgan_enforce_connectivity_scratch_bytes(int B, int H, int W, int nlabels);
+int imgan_enforce_connectivity(const int32_t* labels, int32_t* out, int B, int H, int W, int nlabels,
+                               void* scratch, imgan_stream_t stream);
 
 /* ---- dominant colour (mpeg7Descriptors.py:76-130) ----------------------------
  * Segments are given by an int32 label map (ids 0..nseg-1, <0 ignored).
