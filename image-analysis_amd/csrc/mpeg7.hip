@@ -428,6 +428,8 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
 // and the colour-structure windows of the box on chip.  Definitions: oracle/mpeg7_std.py
 // "per region".  A box of more than RD_CAP cells is left to the caller (counted in too_big).
 constexpr int RD_THREADS = 512, RD_CAP = 24576, RD_WORDS = RD_CAP / 64;
+constexpr int RD_POOL = 4608;                              // 64-bit words: 36 KB >= RD_CAP grey bytes
+typedef uint32_t __attribute__((aligned(1))) u32_any;     // one global_load_dword at any address
 static_assert(RD_CAP < 32768, "the colour structure's sub-sampling factor must stay 1 on chip");
 
 __device__ __forceinline__ int ehd_block_size_dev(int H, int W) {
@@ -449,13 +451,15 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     const uint8_t* __restrict__ img, const int32_t* __restrict__ labels, const int32_t* __restrict__ bbox,
     int H, int W, int nseg, int nbins, HmmdTab T, unsigned long long* __restrict__ cld_sums,
     int32_t* __restrict__ ehd_out, int32_t* __restrict__ csd_out, int32_t* __restrict__ too_big) {
-    __shared__ uint8_t gray[RD_CAP], col[RD_CAP];
-    // bitmaps over the cells of the box, row-major with the box's own pitch: the region's cells,
-    // the cells where an 8 x 8 window fits, and per colour pass the cells of two colours (R) and
-    // their dilation along x (D)
-    __shared__ unsigned long long member[RD_WORDS], fits[RD_WORDS], R[2][RD_WORDS], D[2][RD_WORDS];
-    __shared__ uint32_t tab[64 * 4], hist[256], ehd[96], present[8];
-    __shared__ uint32_t nwin;
+    // pool: first the grey levels of the box's cells (edge histogram), then, for the colour
+    // structure, bitmaps over the cells: per colour of a pass its cells (R) and their dilation
+    // along x (D).  member / fits: the region's cells, and the cells where an 8 x 8 window fits.
+    __shared__ unsigned long long pool[RD_POOL];
+    __shared__ uint8_t col[RD_CAP];
+    __shared__ unsigned long long member[RD_WORDS], fits[RD_WORDS];
+    __shared__ uint32_t tab[64 * 4], hist[256], ehd[96], present[8], cnts[264];
+    __shared__ uint8_t slot_of[256], colour_of[257];
+    uint8_t* gray = reinterpret_cast<uint8_t*>(pool);
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const size_t gs = (size_t)b * nseg + s;
     const int* bb = bbox + gs * 4;
@@ -478,40 +482,63 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     for (int i = tid; i < 256; i += RD_THREADS) hist[i] = 0;
     for (int i = tid; i < 96; i += RD_THREADS) ehd[i] = 0;
     if (tid < 8) present[tid] = 0;
-    if (tid == 0) nwin = 0;
     __syncthreads();
 
     // ---- stage the box; 8 x 8 grid sums of the region's pixels on the way
     const uint8_t* im = img + (size_t)b * H * W * 3;
     const int32_t* lab = labels + (size_t)b * H * W;
     const float inv_bw = 1.0f / (float)bw;
-    for (int i0 = 0; i0 < area; i0 += RD_THREADS) {
-        const int i = i0 + tid;
-        bool mem = false, fit = false;
-        if (i < area) {
-            int yy = (int)((float)i * inv_bw);
-            int xx = i - yy * bw;
-            yy += (xx >= bw) - (xx < 0);                 // the float quotient can be off by one
-            xx = i - yy * bw;
-            fit = xx + 8 <= bw && yy + 8 <= bh;
-            const size_t p = (size_t)(y0 + yy) * W + (x0 + xx);
-            mem = lab[p] == s;
-            const uint8_t* q = im + p * 3;
-            const uint32_t cb = q[0], cg = q[1], cr = q[2];
-            gray[i] = (uint8_t)gray_px(cb, cg, cr);
+    // Four cells per thread and step, every load issued before the first use (a step is bound by
+    // the memory latency of its loads, not by their number); addresses are clamped into the box
+    // instead of branched around, and the three colour bytes come with one unaligned dword load
+    // (the very last pixel of the batch is read one byte early so that the load stays in bounds).
+    constexpr int GU = 4;
+    const size_t last_px = (size_t)gridDim.y * H * W - 1;
+    for (int i0 = 0; i0 < area; i0 += RD_THREADS * GU) {
+        int xx[GU], yy[GU], lbl[GU];
+        uint32_t raw[GU], sh[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = i0 + u * RD_THREADS + tid;
+            const int ic = i < area ? i : area - 1;
+            int y = (int)((float)ic * inv_bw);
+            int x = ic - y * bw;
+            y += (x >= bw) - (x < 0);                    // the float quotient can be off by one
+            x = ic - y * bw;
+            xx[u] = x, yy[u] = y;
+            const size_t p = (size_t)(y0 + y) * W + (x0 + x);
+            lbl[u] = lab[p];
+            const size_t gp = (size_t)b * H * W + p;
+            sh[u] = gp == last_px ? 1u : 0u;
+            raw[u] = *reinterpret_cast<const u32_any*>(im + p * 3 - sh[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int i = i0 + u * RD_THREADS + tid;
+            const bool live = i < area;
+            const bool mem = live && lbl[u] == s;
+            const bool fit = live && xx[u] + 8 <= bw && yy[u] + 8 <= bh;
+            const uint32_t v = raw[u] >> (8u * sh[u]);
+            const uint32_t cb = v & 255u, cg = (v >> 8) & 255u, cr = (v >> 16) & 255u;
+            if (live) gray[i] = (uint8_t)gray_px(cb, cg, cr);
+            int blk = -1;
             if (mem) {
                 const uint32_t c = (uint32_t)hmmd_cell((int)cb, (int)cg, (int)cr, T);
                 col[i] = (uint8_t)c;
                 if (!((present[c >> 5] >> (c & 31u)) & 1u)) atomicOr(&present[c >> 5], 1u << (c & 31u));
-                const int blk = ((yy * 8) / bh) * 8 + (xx * 8) / bw;
+                blk = ((yy[u] * 8) / bh) * 8 + (xx[u] * 8) / bw;
+            }
+            // (one wave-wide sum per block and field instead of these atomics, 64 cells hitting a
+            // handful of LDS words, was measured slower: 10.1 against 7.2 ms on the mosaic)
+            if (blk >= 0) {
                 atomicAdd(&tab[blk * 4], cb);
                 atomicAdd(&tab[blk * 4 + 1], cg);
                 atomicAdd(&tab[blk * 4 + 2], cr);
                 atomicAdd(&tab[blk * 4 + 3], 1u);
             }
+            const unsigned long long mbits = __ballot(mem), fbits = __ballot(fit);   // 64 consecutive cells
+            if (lane == 0 && live) member[i >> 6] = mbits, fits[i >> 6] = fbits;
         }
-        const unsigned long long mbits = __ballot(mem), fbits = __ballot(fit);   // 64 consecutive cells
-        if (lane == 0 && i < area) member[i >> 6] = mbits, fits[i >> 6] = fbits;
     }
     __syncthreads();
     for (int i = tid; i < 64 * 4; i += RD_THREADS) csum[i] = tab[i];
@@ -556,71 +583,83 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     // in [u, u+8) x [v, v+8) has it: the windows of c are the 8 x 8 dilation of c's cells towards
     // the origin.  On bitmaps over the box's cells that is seven shifts by one bit (x) and seven
     // by one row pitch (y); bits that a shift carries across a row end land on origins where no
-    // window fits, which the `fits` bitmap removes before the count.  Two colours per pass; the
-    // last pass takes the region's own bitmap for the number of windows that hold a region pixel.
+    // window fits, which the `fits` bitmap removes before the count.  Slot 0 is the region itself
+    // (the number of windows that hold a region pixel), slots 1.. its colours in ascending order;
+    // a pass takes as many slots as the pool holds bitmaps for (all of them for a typical
+    // superpixel).
+    uint32_t nwin = 0;
     if (bw >= 8 && bh >= 8) {
-        int w8 = 0;
-        uint32_t bits = present[0];
-        auto next_colour = [&]() -> int {               // ascending; -2 when none is left
-            while (bits == 0u && w8 < 7) bits = present[++w8];
-            if (bits == 0u) return -2;
-            const int bit = __ffs((int)bits) - 1;
-            bits &= bits - 1;
-            return w8 * 32 + bit;
-        };
-        bool last = false;
-        while (!last) {
-            // two colours per pass; -1 = the membership pass (the last one); -2 = nothing
-            int c0 = next_colour(), c1 = -2;
-            if (c0 == -2) {
-                c0 = -1;
-                last = true;
-            } else {
-                c1 = next_colour();
-                if (c1 == -2) {
-                    c1 = -1;
-                    last = true;
-                }
-            }
+        if (tid < 256) {
+            const uint32_t c = (uint32_t)tid;
+            uint32_t below = 0;
+            for (uint32_t w = 0; w < (c >> 5); ++w) below += (uint32_t)__popc(present[w]);
+            below += (uint32_t)__popc(present[c >> 5] & ((1u << (c & 31u)) - 1u));
+            const bool here = (present[c >> 5] >> (c & 31u)) & 1u;
+            slot_of[c] = here ? (uint8_t)(1u + below) : (uint8_t)0;   // <= 256 colours: slot 256 wraps
+            if (here) colour_of[1 + below] = (uint8_t)c;
+        }
+        int nslots = 1;
+        for (int w = 0; w < 8; ++w) nslots += __popc(present[w]);
+        const int G = min(nslots, RD_POOL / (2 * nwords));     // >= 6
+        __syncthreads();                                      // the edge histogram is done with `gray`
+        for (int g0 = 0; g0 < nslots; g0 += G) {
+            const int ng = min(G, nslots - g0);
+            unsigned long long* Rb = pool;
+            unsigned long long* Db = pool + (size_t)G * nwords;
+            for (int k = tid; k < ng * nwords; k += RD_THREADS) Rb[k] = 0ull;
+            for (int k = tid; k < ng; k += RD_THREADS) cnts[k] = 0;
+            __syncthreads();
+            // a wave owns the 64-bit word of its 64 consecutive cells: one ballot and one plain
+            // store per slot that occurs among them
             for (int i0 = 0; i0 < area; i0 += RD_THREADS) {
                 const int i = i0 + tid;
-                bool b0 = false, b1 = false;
-                if (i < area && is_member(i)) {
-                    const int c = col[i];
-                    b0 = c0 == -1 || c == c0;
-                    b1 = c1 == -1 || c == c1;
+                int r = -1;
+                const bool mem = i < area && is_member(i);
+                if (mem) {
+                    int sl = slot_of[col[i]];
+                    if (sl == 0) sl = 256;                   // slot 256 is stored as 0 in the byte table
+                    r = sl - g0;
+                    if (r >= ng) r = -1;
                 }
-                const unsigned long long r0 = __ballot(b0), r1 = __ballot(b1);
-                if (lane == 0 && i < area) R[0][i >> 6] = r0, R[1][i >> 6] = r1;
+                if (g0 == 0) {
+                    const unsigned long long all = __ballot(mem);
+                    if (lane == 0 && i < area) Rb[i >> 6] = all;
+                }
+                unsigned long long todo = __ballot(r >= 0);
+                while (todo) {
+                    const int rsel = __builtin_amdgcn_readlane(r, __ffsll((long long)todo) - 1);
+                    const unsigned long long who = __ballot(r == rsel);
+                    if (lane == 0) Rb[(size_t)rsel * nwords + (i >> 6)] = who;
+                    todo &= ~who;
+                }
             }
             __syncthreads();
-            for (int k = tid; k < 2 * nwords; k += RD_THREADS) {
-                const int which = k >= nwords, w = k - which * nwords;
-                const unsigned long long p = R[which][w], n = w + 1 < nwords ? R[which][w + 1] : 0ull;
+            for (int k = tid; k < ng * nwords; k += RD_THREADS) {
+                const int r = k / nwords, w = k - r * nwords;
+                const unsigned long long* Rr = Rb + (size_t)r * nwords;
+                const unsigned long long p = Rr[w], n = w + 1 < nwords ? Rr[w + 1] : 0ull;
                 unsigned long long d = p;
 #pragma unroll
                 for (int dx = 1; dx < 8; ++dx) d |= (p >> dx) | (n << (64 - dx));
-                D[which][w] = d;
+                Db[k] = d;
             }
             __syncthreads();
-            uint32_t cnt0 = 0, cnt1 = 0;
-            for (int k = tid; k < 2 * nwords; k += RD_THREADS) {
-                const int which = k >= nwords, w = k - which * nwords;
-                unsigned long long v = D[which][w];
+            for (int k = tid; k < ng * nwords; k += RD_THREADS) {
+                const int r = k / nwords, w = k - r * nwords;
+                const unsigned long long* Dr = Db + (size_t)r * nwords;
+                unsigned long long v = Dr[w];
 #pragma unroll
-                for (int dy = 1; dy < 8; ++dy) v |= bits_at(D[which], w, dy * bw, nwords);
+                for (int dy = 1; dy < 8; ++dy) v |= bits_at(Dr, w, dy * bw, nwords);
                 const uint32_t c = (uint32_t)__popcll(v & fits[w]);
-                if (which) cnt1 += c;
-                else cnt0 += c;
+                if (c) atomicAdd(&cnts[r], c);
             }
-            cnt0 = wave_sum(cnt0);
-            cnt1 = wave_sum(cnt1);
-            if (lane == 0) {
-                if (cnt0) atomicAdd(c0 == -1 ? &nwin : &hist[c0], cnt0);
-                if (cnt1 && c1 != -2) atomicAdd(c1 == -1 ? &nwin : &hist[c1], cnt1);
+            __syncthreads();
+            for (int r = tid; r < ng; r += RD_THREADS) {
+                const int sl = g0 + r;
+                if (sl == 0) nwin = cnts[r];                   // thread 0 of the first pass
+                else hist[colour_of[sl]] = cnts[r];
             }
-            // R is rewritten only after every thread has passed the barrier behind the D phase;
-            // D only after the next pass's first barrier
+            __syncthreads();                                   // cnts and the pool are reused
         }
     }
     __syncthreads();
