@@ -103,17 +103,56 @@ __global__ __launch_bounds__(256) void rag_accumulate_kernel(
         }
     };
     const int yend = min((int)(blockIdx.y + 1) * RAG_ROWS, H);
-    for (int y = blockIdx.y * RAG_ROWS; y < yend; ++y) {
-    const long long p = (long long)y * W + x;
-    int l = -1;
-    uint32_t raw = 0;
-    if (x < W) {
-        l = lab[p];
-        // the three bytes with one (unaligned) dword load; the very last pixel of the batch is
-        // read one byte early so that the load stays inside the buffer
-        const uint32_t sh = ((long long)b * npix + p == last_px) ? 1u : 0u;
-        raw = *reinterpret_cast<const u32_any*>(im + p * 3 - sh) >> (8u * sh);
+    const int lane = threadIdx.x & 63;
+    // adjacency state: the row above (own column and the columns left / right of it); a lane takes
+    // its neighbours' labels from the lanes beside it, only the two lanes at the wave's ends load
+    // a label of their own for that
+    int pc = -1, pcl = -1, pcr = -1;
+    // what a lane reads from memory for row y: its label, its pixel, and (lanes 0 / 63 only) the
+    // label left / right of the wave's 64 columns
+    struct RowIn {
+        int c, edge;
+        uint32_t raw;
+    };
+    auto fetch = [&](int y, bool pixel) {
+        RowIn r;
+        const long long q = (long long)y * W + x;
+        r.c = x < W ? lab[q] : -1;
+        r.edge = -1;
+        r.raw = 0;
+        if (E) {
+            if (lane == 0 && x > 0 && x <= W) r.edge = lab[q - 1];
+            if (lane == 63 && x + 1 < W) r.edge = lab[q + 1];
+        }
+        if (pixel && x < W) {
+            // the three bytes with one (unaligned) dword load; the very last pixel of the batch is
+            // read one byte early so that the load stays inside the buffer
+            const uint32_t sh = ((long long)b * npix + q == last_px) ? 1u : 0u;
+            r.raw = *reinterpret_cast<const u32_any*>(im + q * 3 - sh) >> (8u * sh);
+        }
+        return r;
+    };
+    auto sides = [&](const RowIn& r, int& cl, int& cr) {
+        cl = __shfl_up(r.c, 1);
+        cr = __shfl_down(r.c, 1);
+        if (lane == 0) cl = r.edge;
+        if (lane == 63) cr = r.edge;
+    };
+    const int ystart = blockIdx.y * RAG_ROWS;
+    if (E && ystart > 0) {
+        const RowIn above = fetch(ystart - 1, false);
+        pc = above.c;
+        sides(above, pcl, pcr);
     }
+    // one row ahead: the loads of row y + 1 are in flight while row y is worked on
+    RowIn next = fetch(ystart, true);
+    for (int y = ystart; y < yend; ++y) {
+    const RowIn here = next;
+    if (y + 1 < yend) next = fetch(y + 1, true);
+    const int l = here.c;
+    const uint32_t raw = here.raw;
+    int cl = -1, cr = -1;
+    if (E) sides(here, cl, cr);
     const bool chg = (l != cur);
     if (__ballot(chg) != 0ull) {                           // wave uniform
         flush(chg);
@@ -128,35 +167,20 @@ __global__ __launch_bounds__(256) void rag_accumulate_kernel(
         a2 += (raw >> 16) & 0xffu;
         an += 1u;
     }
-    // ---- adjacency: E, S, SE, SW neighbours (each unordered 8-neighbour pair once)
-    if (E && l >= 0) {                                    // l >= 0 implies x < W
-        int last = -1;
-        const bool hasS = (y + 1 < H);
-        if (x + 1 < W) {
-            int r = lab[p + 1];
-            if (r >= 0 && r != l) {
-                edge_insert(E, edge_mask, l, r, overflow + b);
-                last = r;
-            }
-            if (hasS) {
-                int r2 = lab[p + W + 1];
-                if (r2 >= 0 && r2 != l && r2 != last) {
-                    edge_insert(E, edge_mask, l, r2, overflow + b);
-                    last = r2;
-                }
-            }
+    // ---- adjacency: W, N, NW, NE neighbours (each unordered 8-neighbour pair once).  A border
+    // runs on for many pixels: a pair this lane met in the row above (vertical border) or the lane
+    // to the left meets in this row (horizontal border) is not looked up again.
+    if (E) {
+        if (l >= 0) {
+            const bool w_ = cl >= 0 && cl != l && !(l == pc && cl == pcl);
+            if (w_) edge_insert(E, edge_mask, l, cl, overflow + b);
+            const bool n_ = pc >= 0 && pc != l && pc != cl && !(lane > 0 && cl == l && pcl == pc);
+            if (n_) edge_insert(E, edge_mask, l, pc, overflow + b);
+            if (pcl >= 0 && pcl != l && pcl != cl && pcl != pc) edge_insert(E, edge_mask, l, pcl, overflow + b);
+            if (pcr >= 0 && pcr != l && pcr != cl && pcr != pc && pcr != pcl)
+                edge_insert(E, edge_mask, l, pcr, overflow + b);
         }
-        if (hasS) {
-            int r = lab[p + W];
-            if (r >= 0 && r != l && r != last) {
-                edge_insert(E, edge_mask, l, r, overflow + b);
-                last = r;
-            }
-            if (x > 0) {
-                int r2 = lab[p + W - 1];
-                if (r2 >= 0 && r2 != l && r2 != last) edge_insert(E, edge_mask, l, r2, overflow + b);
-            }
-        }
+        pc = l, pcl = cl, pcr = cr;
     }
     }
     flush(true);
