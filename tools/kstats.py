@@ -13,6 +13,9 @@ for r in rows:
     name = name.split("(")[0][:60]
     t = float(r["TotalDurationNs"]) / 1e6 / div
     tot += t
-    if t > 0.05:
+    if name.startswith("at::") or "rocclr" in name:      # torch kernels of the input synthesis, not the path
+        tot -= t
+        continue
+    if t > 0.005:
         print("%-62s calls %7.1f  total %9.3f ms  avg %9.1f us" % (name, int(r["Calls"]) / div, t, float(r["AverageNs"]) / 1e3))
 print("sum %.2f ms" % tot)

@@ -12,6 +12,16 @@ from imgan.pipeline import FullPipeline
 
 stage = sys.argv[1] if len(sys.argv) > 1 else "slic"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+if stage == "rag4k":                       # configs[2]: 4 x 3840x2160, K = 2000, two steps
+    from imgan.pipeline import RagPipeline
+    B = min(B, 4)
+    bgr = synth_batch(B, 2160, 3840, 2000, 4321, "cuda")
+    rp = RagPipeline(B, 2160, 3840, 2000)
+    for rep in range(2):
+        rp.step(bgr, check=False)
+    torch.cuda.synchronize()
+    print("done", stage, B)
+    sys.exit(0)
 bgr = synth_batch(B, 1080, 1920, 400, 1234, "cuda")
 pipe = FullPipeline(B, 1080, 1920, 400)
 for rep in range(2):
