@@ -355,7 +355,19 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # IMGAN_BENCH_FORCE_DIST=1: take the RCCL path (process group, barrier, all-gather, max-reduce)
+    # with a single rank too, to exercise it on a one-GPU box; never set by the driver
+    force_dist = os.environ.get("IMGAN_BENCH_FORCE_DIST") == "1" and world == 1
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    # RCCL prints a version banner on stdout when its first communicator comes up; stdout carries
+    # the one JSON line, so file descriptor 1 points at stderr until the result is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -371,7 +383,7 @@ def main():
     pipe = FullPipeline(B, H, W, K, colour_weight=cw, num_iter=num_iter, dominant=8)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -392,7 +404,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -458,8 +470,10 @@ def main():
             del pipe, bgr, index, pending, image_rows, region_rows
             torch.cuda.empty_cache()
             out["configs"] = [run_config_rag(max(args.steps, 3), 1), run_config_mosaic(2, 1)]
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -345,12 +345,9 @@ extern "C" int imgan_rag_merge_device(const uint64_t* sums, const uint64_t* edge
     if (K > MG_MAXK)
         return imgan::fail(imgan::E_RANGE, "imgan_rag_merge_device: more than 4096 labels per image; use "
                                            "imgan_rag_merge_host");
-    static bool attr_set = false;
-    if (!attr_set) {
-        IMGAN_HIP(hipFuncSetAttribute((const void*)rag_merge_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)MG_LDS));
-        attr_set = true;
-    }
+    // per device, so set on every call (a process may drive several GPUs)
+    IMGAN_HIP(hipFuncSetAttribute((const void*)rag_merge_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)MG_LDS));
     hipLaunchKernelGGL(rag_merge_kernel, dim3((unsigned)B), dim3(MG_THREADS), MG_LDS, (hipStream_t)stream,
                        (const unsigned long long*)sums, (const unsigned long long*)edges,
                        (long long)edge_cap, overflow, K, c_factor, lut_out, status);
