@@ -308,6 +308,46 @@ def run_config_mosaic(steps, warmup):
     return rec
 
 
+def run_config_bear(steps, warmup, cw=15, k=8):
+    """configs[0]: the reference's own CPU case, slic.py + mpeg7Descriptors on data/bear.jpg at full
+    size (1573 x 1050, K = 200 -> S = 90, 176 superpixels).  The photograph does not travel with the
+    repository, so a synthetic image of that shape stands in; GPU step and CPU leg on the same image
+    size (the CPU leg is the whole workload here: one image)."""
+    from imgan.pipeline import FullPipeline
+    from oracle.synth import voronoi_image
+    from oracle.color import bgr2lab_u8
+    from oracle import c_oracle, mpeg7_std as M
+    B, H, W, K = 1, 1050, 1573, 200
+    bgr = synth_batch(B, H, W, K, 7, "cuda")
+    pipe = FullPipeline(B, H, W, K, colour_weight=cw, num_iter=10, dominant=k)
+    for _ in range(warmup):
+        pipe.step(bgr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step(bgr)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    img = voronoi_image(H, W, K, seed=7)
+    t0 = time.perf_counter()
+    lab = bgr2lab_u8(img)
+    c_oracle.path_batch(lab[None], K, cw, 10, k, 1)
+    M.colour_layout(img)
+    M.edge_histogram_counts(img)
+    M.colour_structure_counts(img)
+    t_cpu = time.perf_counter() - t0
+    npix = H * W
+    return {"config": "configs[0]: one %dx%d image (bear.jpg's size, synthetic), K=%d (n=%d, S=%d), Lab + SLIC + "
+                      "CLD / EHD / CSD + dominant colours k=%d per superpixel; launch-latency bound at this size" %
+                      (W, H, K, pipe.n, pipe.slic.S, k),
+            "value": round(npix * steps / dt / 1e6, 2), "unit": "megapixels/sec",
+            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "cpu_baseline": {"value": round(npix / 1e6 / t_cpu, 3), "unit": "megapixels/sec", "cores": 1,
+                             "kind": "port",
+                             "sample": "the same workload, whole: numpy Lab + C SLIC and dominant colours + numpy "
+                                       "CLD / EHD / CSD, 1 thread, %.2f s" % t_cpu}}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` on its own: start N ranks (one per GPU, RCCL) as a child job and
     pass its output and exit code on.  Nothing in this process has touched the GPU yet."""
@@ -469,7 +509,8 @@ def main():
         if world == 1 and not args.no_configs:
             del pipe, bgr, index, pending, image_rows, region_rows
             torch.cuda.empty_cache()
-            out["configs"] = [run_config_rag(max(args.steps, 3), 1), run_config_mosaic(2, 1)]
+            out["configs"] = [run_config_bear(5, 2), run_config_rag(max(args.steps, 3), 1),
+                              run_config_mosaic(2, 1)]
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

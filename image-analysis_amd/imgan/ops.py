@@ -220,18 +220,16 @@ def rag_accumulate(img, labels, K, want_edges=True, edge_cap=None):
         sums.zero_()
         check(lib.imgan_rag_accumulate(_ptr(img), _ptr(labels), B, H, W, int(K), _ptr(sums),
                                        _ptr(table), cap, _ptr(overflow), _stream()))
-        if int(overflow.max().item()) == 0:
+        if not overflow.cpu().numpy().any():
             break
         cap *= 4                                     # pathological adjacency: retry larger
-    # one sort and one transfer for the whole batch: keys are positive, so the empty slots (0)
-    # sort to the front of every row; (u+1)<<32 | (v+1) orders lexicographically by (u, v)
-    ordered, _ = torch.sort(table, dim=1)
-    counts = (table != 0).sum(dim=1).cpu().numpy()
-    width = int(counts.max()) if B else 0
-    host = ordered[:, cap - width:].cpu().numpy() if width else np.zeros((B, 0), dtype=np.int64)
+    # this form hands host lists to the class API: the hash sets cross to the host as they are and
+    # are ordered there ((u+1)<<32 | (v+1) orders lexicographically by (u, v)); the batch path
+    # (RagPlan) keeps them on the device
+    host = table.cpu().numpy()
     edges = []
     for b in range(B):
-        keys = host[b, width - int(counts[b]):]
+        keys = np.sort(host[b][host[b] != 0])
         uv = np.stack([(keys >> 32) - 1, (keys & 0xffffffff) - 1], axis=1).astype(np.int32)
         edges.append(uv.reshape(-1, 2))
     return sums, edges
