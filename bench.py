@@ -214,6 +214,16 @@ def pmc_traffic(key, kernel, npix):
     return int(e["bytes_per_px"] * npix) if e else None
 
 
+def dcd_traffic(key, npix):
+    """HBM bytes of one imgan_dcd_segments_listed call: the sort pass, the plan and the three tier
+    launches (pmc_traffic.json holds the mean over the launches of a kernel name)."""
+    parts = [pmc_traffic(key, "seg_scatter_kernel", npix), pmc_traffic(key, "seg_plan_kernel", npix),
+             pmc_traffic(key, "dcd_segment_kernel", npix)]
+    if any(p is None for p in parts):
+        return None
+    return parts[0] + parts[1] + 3 * parts[2]
+
+
 def run_config_rag(steps, warmup):
     """configs[2]: 16 x 3840x2160, K = 2000, median 7 + Lab + SLIC + RAG merge + relabel."""
     from imgan.pipeline import RagPipeline
@@ -486,15 +496,18 @@ def main():
                                     "Lab + SLIC + CLD + EHD + CSD(256) + DCD(k=8 per superpixel, "
                                     "%.1f Lloyd rounds per pixel on chip)" % t_bar),
                        "global_batch": B * world, "parallelism": "batch-sharded x%d" % world},
-            # the dominant kernel by time; the two tiers of dcd_segment_kernel (one launch each, the
-            # second for the few superpixels too large for the first) are one pass over the segments
+            # the dominant kernel by time: one C call (imgan_dcd_segments_listed) = the pass that sorts
+            # the pixels by segment + the three capacity tiers of dcd_segment_kernel, one launch each
             "roofline": roofline_line(
-                "dcd_segment_kernel", stage_ms["dcd_segments"], dcd_survey, npix,
-                traffic=pmc_traffic(key, "dcd_segment_kernel", npix), profile=prof, bound="valu/lds",
-                note="largest share of the step time.  Algorithmic bytes = SURVEY 8d's streaming figure "
+                "dcd_segment_kernel x3 tiers (+seg_scatter_kernel, seg_plan_kernel)",
+                stage_ms["dcd_segments"], dcd_survey, npix,
+                traffic=dcd_traffic(key, npix), profile=prof, bound="valu/lds",
+                note="largest share of the step time; timed around the C call, i.e. the sum of the five "
+                     "kernels it launches back to back.  Algorithmic bytes = SURVEY 8d's streaming figure "
                      "8*T + 13*P B/px with T = %.1f measured Lloyd rounds per pixel, P = 1; the rounds run "
-                     "in LDS, so the HBM traffic it must move is 8 B/px and the kernel is VALU / LDS "
-                     "bound" % t_bar),
+                     "in LDS, so the HBM traffic it must move is 24 B/px (7 labels + Lab in, 8 list out, "
+                     "8 list in, 1 assignment out; traffic above that is the sort's partial lines) and "
+                     "the kernel is VALU / LDS bound" % t_bar),
             "roofline_kernels": others,
             "dcd_segments_at_round_cap": pipe.segments_at_round_cap(),
             "path": {"bytes_per_px": round(path_bytes_px, 1),

@@ -13,6 +13,11 @@
 //
 // Segments whose pixel count exceeds the LDS capacity (or whose bounding box has more than
 // 65535 pixels) are left to the streaming path: SegState.handled stays 0 for them.
+//
+// Two front ends feed the same body: the box gather (imgan_dcd_segments / _boxed: every
+// workgroup scans its segment's bounding box; no memory beyond the boxes) and the pixel lists
+// (imgan_dcd_segments_listed: one pass sorts all pixels by segment first; 8 B of scratch per
+// pixel, every segment dispatched to the tier that fits it).
 #include "common.h"
 #include "../../include/imgan.h"
 #include "dcd_common.h"
@@ -21,9 +26,10 @@ using namespace imgan_dcd;
 
 namespace {
 
-// Two capacity tiers: most segments (superpixels) fit the small tier, which leaves room for
-// two workgroups per CU; the few larger ones are retried by the large tier (one workgroup per
-// CU); only what exceeds that goes to the streaming path.
+// Capacity tiers: most segments (superpixels) fit the small tier, which leaves room for two
+// workgroups per CU; the few larger ones go to the large tier (one workgroup per CU); only what
+// exceeds that goes to the streaming path.  The listed mode, which knows every segment's size
+// before it starts, adds a tier below the small one (three workgroups per CU).
 #ifdef IMGAN_SEG_TIMING
 // phase clocks of thread 0, summed over blocks (tools/seg_timing.py; never built into the product)
 __device__ unsigned long long seg_timing[16];
@@ -52,6 +58,8 @@ typedef uint32_t __attribute__((aligned(1))) u32_unaligned;   // one global_load
 // Lloyd rounds are latency bound per workgroup, and wave counts that do not divide by four leave
 // one SIMD holding the others up at every barrier.
 constexpr int CAP_SMALL = 12288, THREADS_SMALL = 768;       // 6 B of LDS per pixel
+// listed mode only: three workgroups per CU for the segments that leave room for them
+constexpr int CAP_TINY = 7680, THREADS_TINY = 512;
 constexpr int CAP_SMALL_K16 = 10752;   // 9 .. 16 colours: twice the accumulators, still two workgroups per CU
 constexpr int CAP_LARGE = 22528, THREADS_LARGE = 1024;     // >= 4 S^2 of the 1080p / K=400 grid
 // The small tier packs {count, sum0} and {sum1, sum2} into 16-bit halves of two words per
@@ -158,6 +166,242 @@ __global__ void seg_bbox_init_kernel(int* __restrict__ bbox, int nsegs) {
     bb[3] = -1;
 }
 
+// ---- pixel lists (imgan_dcd_segments_listed).  With the pixel count of every segment known up
+// front (the last SLIC round has it), one streaming pass sorts the pixels by segment: every
+// segment owns a contiguous run of {Lab, y << 16 | x} entries.  The segment kernel then loads its
+// run with straight reads instead of scanning its bounding box (about 2.5 cells per pixel for a
+// superpixel, with a ballot and an LDS atomic per 64 cells), and every segment goes directly to
+// the capacity tier that fits it.
+struct SegLists {
+    int* hdr;               // [16]: 0..2 length of the tier lists, 4..6 their ticket counters
+    uint32_t* offsets;      // [nsegs + 1] start of every segment's run (clamped to the pixel total)
+    uint32_t* cursor;       // [nsegs] entries written so far
+    int* tier[3];           // [nsegs] each: segment ids by tier
+    uint32_t* spix;         // [B*H*W] Lab of the listed pixels
+    uint32_t* sxy;          // [B*H*W] y << 16 | x
+};
+
+size_t seg_lists_bytes(size_t nsegs, size_t npx) {
+    return 256 + imgan::align_up((nsegs + 1) * 4, 256) + 4 * imgan::align_up(nsegs * 4, 256) +
+           2 * imgan::align_up(npx * 4, 256);
+}
+
+SegLists bind_lists(void* scratch, size_t nsegs, size_t npx) {
+    char* p = (char*)scratch;
+    SegLists L;
+    L.hdr = (int*)p;
+    p += 256;
+    L.offsets = (uint32_t*)p;
+    p += imgan::align_up((nsegs + 1) * 4, 256);
+    L.cursor = (uint32_t*)p;
+    p += imgan::align_up(nsegs * 4, 256);
+    for (int t = 0; t < 3; ++t) {
+        L.tier[t] = (int*)p;
+        p += imgan::align_up(nsegs * 4, 256);
+    }
+    L.spix = (uint32_t*)p;
+    p += imgan::align_up(npx * 4, 256);
+    L.sxy = (uint32_t*)p;
+    return L;
+}
+
+// Room a tier needs for a segment: its pixels, and the 2-byte cell grid of the coherence pass over
+// the bounding box (which also keeps cell offsets within 16 bits).
+__device__ __forceinline__ bool tier_fits(long long n, long long area, int cap) {
+    return cap > 0 && n <= cap && area <= 65535 && area * 2 + 8 <= (long long)cap * 6;
+}
+
+// One workgroup: running sum of the counts -> offsets, cursors cleared, every segment put on the
+// list of the smallest tier that holds it (or counted in n_big: left to the streaming path).
+__global__ __launch_bounds__(1024) void seg_plan_kernel(const int32_t* __restrict__ counts,
+                                                        const int* __restrict__ bbox, int nsegs,
+                                                        int H, int W, unsigned long long npx,
+                                                        SegLists L, int cap0, int cap1, int cap2,
+                                                        int* __restrict__ n_big) {
+    __shared__ unsigned long long wave_sum[16];
+    __shared__ unsigned long long carry;
+    __shared__ int fill[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0ull;
+    if (tid < 4) fill[tid] = 0;
+    __syncthreads();
+    for (int base = 0; base < nsegs; base += 1024) {
+        const int i = base + tid;
+        const int c = i < nsegs ? max(counts[i], 0) : 0;
+        unsigned long long incl = (unsigned long long)c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (int w = 0; w < wave; ++w) before += wave_sum[w];
+        const unsigned long long start = before + incl - (unsigned long long)c;
+        if (i < nsegs) {
+            const unsigned long long s0 = start < npx ? start : npx;
+            const unsigned long long s1 = start + c < npx ? start + c : npx;
+            L.offsets[i] = (uint32_t)s0;
+            L.cursor[i] = 0u;
+            const long long n = (long long)(s1 - s0);
+            const int* bb = bbox + (size_t)i * 4;
+            const int xmin = max(bb[0], 0), ymin = max(bb[1], 0);
+            const int xmax = min(bb[2], W - 1), ymax = min(bb[3], H - 1);
+            const bool empty = xmax < xmin || ymax < ymin || n == 0;
+            const long long area = empty ? 0 : (long long)(xmax - xmin + 1) * (ymax - ymin + 1);
+            const int t = tier_fits(n, area, cap0) ? 0 : tier_fits(n, area, cap1) ? 1
+                          : tier_fits(n, area, cap2) ? 2 : 3;
+            const int at = atomicAdd(&fill[t], 1);
+            if (t < 3) L.tier[t][at] = i;
+        }
+        __syncthreads();
+        if (tid == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        L.offsets[nsegs] = (uint32_t)(carry < npx ? carry : npx);
+        atomicAdd(n_big, fill[3]);
+    }
+    if (tid < 3) {
+        L.hdr[tid] = fill[tid];
+        L.hdr[4 + tid] = 0;
+    }
+}
+
+// The pass that fills the runs (COUNT_ONLY: just counts the pixels of every label, for callers
+// that have no counts).  One block = 256 columns x SC_ROWS rows, every lane one column.  The
+// labels of a block are tallied in a small LDS table (one LDS atomic per run of equal labels in a
+// wave row, which also ranks the pixels of the run); then one global atomic per label and block
+// reserves the block's share of the segment's run, and the pixels are written behind it.
+constexpr int SC_ROWS = 8, SC_SLOTS = 128;
+
+struct ScatterTable {
+    int key[SC_SLOTS];
+    uint32_t cnt[SC_SLOTS];
+    uint32_t base[SC_SLOTS];
+    uint32_t end[SC_SLOTS];
+};
+
+template <bool COUNT_ONLY>
+__global__ __launch_bounds__(256) void seg_scatter_kernel(const uint8_t* __restrict__ lab,
+                                                          const int32_t* __restrict__ labels, int B,
+                                                          int H, int W, int nseg, SegLists L,
+                                                          int32_t* __restrict__ counts) {
+    __shared__ ScatterTable T;
+    const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int y0 = blockIdx.y * SC_ROWS;
+    const int x = blockIdx.x * 256 + tid;
+    const int xc = x < W ? x : W - 1;
+    if (tid < SC_SLOTS) {
+        T.key[tid] = -1;
+        T.cnt[tid] = 0u;
+    }
+    const size_t last_px = (size_t)B * H * W - 1;
+    int lbl[SC_ROWS];
+    uint32_t px[SC_ROWS];
+#pragma unroll
+    for (int u = 0; u < SC_ROWS; ++u) {                 // all loads first, clamped not branched
+        const int y = y0 + u < H ? y0 + u : H - 1;
+        const size_t gp = ((size_t)b * H + y) * W + xc;
+        lbl[u] = labels[gp];
+        if (!COUNT_ONLY) {
+            const uint32_t sh = gp == last_px ? 1u : 0u;
+            px[u] = *reinterpret_cast<const u32_unaligned*>(lab + gp * 3 - sh) >> (8u * sh);
+        }
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // where[u]: table slot | rank in the block's share << 8; -1: no pixel; slot 255: table full
+    int where[SC_ROWS];
+#pragma unroll
+    for (int u = 0; u < SC_ROWS; ++u) {
+        const bool ok = x < W && y0 + u < H && lbl[u] >= 0 && lbl[u] < nseg;
+        int pending = ok ? lbl[u] : -1;
+        where[u] = -1;
+        while (true) {
+            const unsigned long long act = __ballot(pending >= 0);
+            if (act == 0ull) break;
+            const int leader = __ffsll((long long)act) - 1;
+            const int cur = __shfl(pending, leader);
+            const bool mine = pending == cur;
+            const unsigned long long who = __ballot(mine);
+            int idx = 255, first = 0;
+            if (lane == leader) {
+                int probe_at = (int)(((uint32_t)cur * 0x9e3779b1u) >> 25);
+                for (int probe = 0; probe < SC_SLOTS; ++probe) {
+                    const int old = atomicCAS(&T.key[probe_at], -1, cur);
+                    if (old == -1 || old == cur) {
+                        idx = probe_at;
+                        break;
+                    }
+                    probe_at = (probe_at + 1) & (SC_SLOTS - 1);
+                }
+                if (idx != 255) first = (int)atomicAdd(&T.cnt[idx], (uint32_t)__popcll(who));
+            }
+            idx = __shfl(idx, leader);
+            first = __shfl(first, leader);
+            if (mine) {
+                where[u] = idx | ((first + __popcll(who & below)) << 8);
+                pending = -1;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < SC_SLOTS && T.key[tid] >= 0) {
+        const size_t gs = (size_t)b * nseg + T.key[tid];
+        if (COUNT_ONLY) {
+            atomicAdd(&counts[gs], (int)T.cnt[tid]);
+        } else {
+            T.base[tid] = L.offsets[gs] + atomicAdd(&L.cursor[gs], T.cnt[tid]);
+            T.end[tid] = L.offsets[gs + 1];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SC_ROWS; ++u) {
+        const uint32_t xy = ((uint32_t)(y0 + u) << 16) | (uint32_t)x;
+        if (where[u] >= 0 && (where[u] & 255) != 255) {
+            if (!COUNT_ONLY) {
+                const int slot = where[u] & 255;
+                // 64-bit: the cursor of a label map that disagrees with the counts may run on
+                const unsigned long long dst = (unsigned long long)T.base[slot] + (uint32_t)(where[u] >> 8);
+                if (dst < T.end[slot]) {
+                    L.spix[dst] = px[u] & 0xffffffu;
+                    L.sxy[dst] = xy;
+                }
+            }
+        }
+        // more labels in the block than table slots: these runs reserve their places one by one
+        int pending = (where[u] >= 0 && (where[u] & 255) == 255) ? lbl[u] : -1;
+        while (true) {
+            const unsigned long long act = __ballot(pending >= 0);
+            if (act == 0ull) break;
+            const int leader = __ffsll((long long)act) - 1;
+            const int cur = __shfl(pending, leader);
+            const bool mine = pending == cur;
+            const unsigned long long who = __ballot(mine);
+            const size_t gs = (size_t)b * nseg + cur;
+            if (COUNT_ONLY) {
+                if (lane == leader) atomicAdd(&counts[gs], __popcll(who));
+            } else {
+                uint32_t first = 0;
+                if (lane == leader) first = atomicAdd(&L.cursor[gs], (uint32_t)__popcll(who));
+                first = (uint32_t)__shfl((int)first, leader);
+                if (mine) {
+                    const unsigned long long dst =
+                        (unsigned long long)L.offsets[gs] + first + (uint32_t)__popcll(who & below);
+                    if (dst < L.offsets[gs + 1]) {
+                        L.spix[dst] = px[u] & 0xffffffu;
+                        L.sxy[dst] = xy;
+                    }
+                }
+            }
+            if (mine) pending = -1;
+        }
+    }
+}
+
 // ---- union-find on 16-bit parents in LDS (the hardware has no 16-bit LDS atomics: a
 // compare-and-swap on the containing word stands in for atomicMin)
 // find with path halving.  The halving store may race with a concurrent atomic_min16 on the
@@ -204,16 +448,21 @@ __device__ __forceinline__ void unite16(uint16_t* par, uint32_t a, uint32_t b) {
     }
 }
 
-// One segment, start to finish, by the whole workgroup.  FIRST: the small tier visits every
-// segment and puts those that do not fit on the retry list; the large tier works through that
-// list and counts what is still too large (left to the streaming path).
-template <int KM, int CAP, int THREADS, bool FIRST>
+// One segment, start to finish, by the whole workgroup.  MODE_FIRST: the small tier visits every
+// segment, gathers its pixels from its bounding box and puts those that do not fit on the retry
+// list; MODE_RETRY: the large tier works through that list and counts what is still too large
+// (left to the streaming path); MODE_LISTED: the pixels come from the segment's run of the pixel
+// lists, and the plan kernel has already chosen a tier that holds them.
+constexpr int MODE_FIRST = 0, MODE_RETRY = 1, MODE_LISTED = 2;
+
+template <int KM, int CAP, int THREADS, int MODE>
 __device__ __forceinline__ void segment_body(
     unsigned char* smem, const int b, const int s, const int B, const uint8_t* __restrict__ lab,
     const int32_t* __restrict__ labels, int H, int W, int nseg, int k, int use_hash, uint32_t seed,
     float* __restrict__ centres, uint8_t* __restrict__ assign, SegState* __restrict__ seg,
     unsigned long long* __restrict__ stats, const int* __restrict__ bbox, int* __restrict__ retry,
-    int* __restrict__ big_count, int max_rounds) {
+    int* __restrict__ big_count, int max_rounds, const SegLists& L) {
+    constexpr bool FIRST = MODE == MODE_FIRST;
     uint32_t* pix = reinterpret_cast<uint32_t*>(smem);                    // Lab | assign << 24
     uint16_t* pos = reinterpret_cast<uint16_t*>(pix + CAP);               // offset in the bbox
     constexpr bool PACKED = (CAP / 64) * 255 < 65536;
@@ -230,11 +479,15 @@ __device__ __forceinline__ void segment_body(
     int& s_done = flags[1];
 
     const size_t gs = (size_t)b * nseg + s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int tid_ = threadIdx.x;
+    // the listed mode calls this in a loop: without the fence the compiler computes everything that
+    // depends on the thread index alone once, ahead of the loop, and keeps it all in registers
+    if (MODE == MODE_LISTED) asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
 #ifdef IMGAN_SEG_TIMING
     unsigned long long t_last_ = wall_clock64();
 #endif
-    if (!FIRST && seg[gs].handled) return;
+    if (MODE == MODE_RETRY && seg[gs].handled) return;
     const int* bb = bbox + gs * 4;
     // clamped into the image: the boxes may come from the caller (imgan_dcd_segments_boxed), and a
     // box outside the image must not turn into a read outside the buffers
@@ -247,7 +500,12 @@ __device__ __forceinline__ void segment_body(
     st.handled = 1;
     st.pad = 0;
     unsigned long long* out = stats + gs * k * 8;
-    if (xmax < xmin || ymax < ymin) {                   // segment id without pixels
+    uint32_t run_at = 0, run_n = 0;
+    if (MODE == MODE_LISTED) {
+        run_at = L.offsets[gs];
+        run_n = min(L.offsets[gs + 1] - run_at, L.cursor[gs]);
+    }
+    if (xmax < xmin || ymax < ymin || (MODE == MODE_LISTED && run_n == 0)) {   // segment id without pixels
         if (tid == 0) seg[gs] = st;
         for (int i = tid; i < k * 8; i += THREADS) out[i] = 0ull;
         return;
@@ -255,10 +513,48 @@ __device__ __forceinline__ void segment_body(
     const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
     const int area = bw * bh;
     const size_t img = (size_t)b * H * W;
-    // positions are kept as 16-bit offsets, and the coherence pass lays a 3-byte cell grid of
+    // positions are kept as 16-bit offsets, and the coherence pass lays a 2-byte cell grid of
     // the box over the pixel store
-    bool big = (long long)bw * bh > 65535 || (long long)bw * bh * 3 + 8 > (long long)CAP * 6;
-    if (!big) {
+    bool big = (long long)bw * bh > 65535 || (long long)bw * bh * 2 + 8 > (long long)CAP * 6;
+    if (MODE == MODE_LISTED) {
+        // ---- the segment's run, straight into LDS.  (A box that does not hold the pixel -- boxes
+        // and counts come from the caller -- must not turn into an offset outside the cell grid.)
+        if (tid == 0) s_n = (int)min(run_n, (uint32_t)CAP);
+        if (tid < KM) slots[tid] = ~0ull;
+        __syncthreads();
+        const int nrun = (int)min(run_n, (uint32_t)CAP);
+        const bool kpow2 = (k & (k - 1)) == 0;
+        constexpr int LU = 4;                          // loads in flight per thread
+        for (int i0 = 0; i0 < nrun; i0 += THREADS * LU) {
+            uint32_t v[LU], xy[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = min(i0 + u * THREADS + tid, nrun - 1);
+                v[u] = L.spix[run_at + i];
+                xy[u] = L.sxy[run_at + i];
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * THREADS + tid;
+                if (i >= nrun) continue;
+                const int x = min(max((int)(xy[u] & 0xffffu), xmin), xmax);
+                const int y = min(max((int)(xy[u] >> 16), ymin), ymax);
+                pix[i] = v[u] & 0xffffffu;
+                pos[i] = (uint16_t)(__mul24(y - ymin, bw) + (x - xmin));
+                if (use_hash) {
+                    const uint32_t p = (uint32_t)(__mul24(y, W) + x);
+                    const uint32_t h = mix32(p * 0x9e3779b1u + seed);
+                    const unsigned long long key = ((unsigned long long)h << 32) | (unsigned long long)p;
+                    unsigned long long* sl = &slots[kpow2 ? (h & (uint32_t)(k - 1)) : h % (uint32_t)k];
+                    if (key < *sl) atomicMin(sl, key);
+                }
+            }
+        }
+        SEG_MARK(7)
+        __syncthreads();
+        SEG_MARK(1)
+        big = false;
+    } else if (!big) {
         if (tid == 0) s_n = 0;
         if (tid < KM) slots[tid] = ~0ull;
         __syncthreads();
@@ -332,6 +628,11 @@ __device__ __forceinline__ void segment_body(
         __syncthreads();
         SEG_MARK(1)
         big = s_n > CAP;
+        if (!big && s_n == 0) {                         // a box (the caller's) without the label in it
+            if (tid == 0) seg[gs] = st;
+            for (int i = tid; i < k * 8; i += THREADS) out[i] = 0ull;
+            return;
+        }
     }
     if (big) {                                          // too large for this tier
         if (tid == 0) {
@@ -396,13 +697,14 @@ __device__ __forceinline__ void segment_body(
     for (int i = tid; i < k * WORDS * 64; i += THREADS) acc[i] = 0;
     __syncthreads();
     while (true) {
-        // centres in registers, two per packed fp32 operand (v_pk_add/mul_f32: IEEE per half)
-        f32x2 c0[KM / 2], c1[KM / 2], c2[KM / 2];
+        // centres in registers (plain fp32 operations: a packed v_pk_*_f32 takes the issue slots of
+        // the two operations it replaces on this chip, and dependent ones need a wait state on top)
+        float c0[KM], c1[KM], c2[KM];
 #pragma unroll
-        for (int jj = 0; jj < KM / 2; ++jj) {
-            c0[jj] = *reinterpret_cast<const f32x2*>(cen + 2 * jj);
-            c1[jj] = *reinterpret_cast<const f32x2*>(cen + KM + 2 * jj);
-            c2[jj] = *reinterpret_cast<const f32x2*>(cen + 2 * KM + 2 * jj);
+        for (int j = 0; j < KM; ++j) {
+            c0[j] = cen[j];
+            c1[j] = cen[KM + j];
+            c2[j] = cen[2 * KM + j];
         }
         for (int i = tid; i < n; i += THREADS) {
             const uint32_t v = pix[i];
@@ -415,21 +717,16 @@ __device__ __forceinline__ void segment_body(
             // q >= +0, so the float order is the order of the bit patterns: the cluster index
             // rides in the low mantissa bits (IDXM + 1 ulp of slack, covered by NEAR) and one
             // unsigned min / med3 per cluster tracks the smallest and second smallest q.
-            const f32x2 F0 = {f0, f0}, F1 = {f1, f1}, F2 = {f2, f2};
             uint32_t best = 0xffffffffu, second = 0xffffffffu;
 #pragma unroll
-            for (int jj = 0; jj < KM / 2; ++jj) {
+            for (int j = 0; j < KM; ++j) {
                 // fused multiply-adds: q differs from the literal (d0^2 + d1^2) + d2^2 by a few
                 // 2^-24 relative roundings, far inside the margin that NEAR leaves
-                const f32x2 d0 = F0 - c0[jj], d1 = F1 - c1[jj], d2 = F2 - c2[jj];
-                const f32x2 q = __builtin_elementwise_fma(
-                    d2, d2, __builtin_elementwise_fma(d1, d1, d0 * d0));
-                const uint32_t kx = (__float_as_uint(q.x) & ~IDXM) | (uint32_t)(2 * jj);
-                const uint32_t ky = (__float_as_uint(q.y) & ~IDXM) | (uint32_t)(2 * jj + 1);
-                second = umed3(kx, best, second);
-                best = min(best, kx);
-                second = umed3(ky, best, second);
-                best = min(best, ky);
+                const float d0 = f0 - c0[j], d1 = f1 - c1[j], d2 = f2 - c2[j];
+                const float q = __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0));
+                const uint32_t kq = (__float_as_uint(q) & ~IDXM) | (uint32_t)j;
+                second = umed3(kq, best, second);
+                best = min(best, kq);
             }
             int bi = (int)(best & IDXM);
             if (__builtin_expect(__fmul_rn(__uint_as_float(second), NEAR) < __uint_as_float(best), 0)) {
@@ -682,7 +979,9 @@ __device__ __forceinline__ void segment_body(
 
     // ---- spatial coherence (:40-74, :118-127): largest 8-connected component of every
     // cluster, found on chip.  Each thread takes its pixels (cell in the box, cluster) into
-    // registers; the pixel store is then reused as a grid over the box: parent u16 + cluster u8.
+    // registers; the pixel store is then reused as a grid over the box: first the cluster of every
+    // cell (u8), from which each cell picks its link (kept in its register as a direction), then,
+    // in the same place, the parents (u16).
     constexpr int NPT = CAP / THREADS;
     static_assert(NPT * THREADS == CAP, "CAP must be a multiple of the block size");
     uint32_t keep[NPT];
@@ -692,7 +991,7 @@ __device__ __forceinline__ void segment_body(
         keep[t] = i < n ? ((uint32_t)pos[i] | ((pix[i] >> 24) << 16)) : 0xffffffffu;
     }
     uint16_t* par = reinterpret_cast<uint16_t*>(smem);
-    uint8_t* cls = smem + (((size_t)area * 2 + 3) & ~(size_t)3);
+    uint8_t* cls = smem;
     uint32_t* largest = reinterpret_cast<uint32_t*>(slots);
     __syncthreads();
     SEG_MARK(9)
@@ -723,10 +1022,18 @@ __device__ __forceinline__ void segment_body(
             const bool n_ = up && cls[cell - bw] == c, w_ = lf && cls[cell - 1] == c;
             const bool nw = up && lf && cls[cell - bw - 1] == c;
             const bool ne = up && rt && cls[cell - bw + 1] == c;
-            const uint32_t link = n_ ? cell - bw : w_ ? cell - 1 : nw ? cell - bw - 1
-                                                  : ne ? cell - bw + 1 : cell;
-            par[cell] = (uint16_t)link;
+            // bits 26-28: 0 self, 1 N, 2 W, 3 NW, 4 NE
+            keep[t] |= (n_ ? 1u : w_ ? 2u : nw ? 3u : ne ? 4u : 0u) << 26;
             if (!n_ && (w_ || nw) && ne) keep[t] |= 0x2000000u;
+        }
+    __syncthreads();                                    // every cluster byte has been read
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu) {
+            const uint32_t cell = keep[t] & 0xffffu, dir = (keep[t] >> 26) & 7u;
+            const uint32_t link = dir == 1u ? cell - bw : dir == 2u ? cell - 1 : dir == 3u ? cell - bw - 1
+                                                        : dir == 4u ? cell - bw + 1 : cell;
+            par[cell] = (uint16_t)link;
         }
     __syncthreads();
     SEG_MARK(12)
@@ -746,7 +1053,7 @@ __device__ __forceinline__ void segment_body(
             const uint32_t cell = keep[t] & 0xffffu;
             const uint32_t root = find16(par, cell);
             par[cell] = (uint16_t)root;                 // shortens the walks of later cells
-            keep[t] = root | (keep[t] & 0xff0000u) | (root == cell ? 0x1000000u : 0u);
+            keep[t] = root | (keep[t] & 0xff0000u) | (root == cell ? 0x1000000u : 0u);   // drops bits 25-28
         }
     __syncthreads();
     SEG_MARK(14)
@@ -784,49 +1091,75 @@ __device__ __forceinline__ void segment_body(
     }
 }
 
-template <int KM, int CAP, int THREADS, bool FIRST>
-__global__ __launch_bounds__(THREADS) void dcd_segment_kernel(
+// LDS of one workgroup: the layout at the top of segment_body; the last 16 bytes are its flags
+// (s_n, s_done) and the ticket of the listed mode
+__host__ __device__ constexpr size_t seg_lds_bytes(int km, int cap) {
+    return (size_t)cap * 6 + (size_t)km * ((cap / 64) * 255 < 65536 ? 3 : 4) * 64 * 4 + (size_t)km * 8 +
+           (size_t)km * 3 * 4 * 2 + (size_t)km * 4 * 4 + (size_t)km * 3 * 4 + 16;
+}
+
+// waves per SIMD when as many workgroups as the LDS allows share a CU: the register budget the
+// compiler is held to (the listed mode's body otherwise settles above it, and a workgroup fewer fits)
+constexpr int seg_waves_per_simd(int km, int cap, int threads) {
+    return (threads / 256) * (int)((160 * 1024) / seg_lds_bytes(km, cap));
+}
+
+template <int KM, int CAP, int THREADS, int MODE>
+__global__ __launch_bounds__(THREADS, seg_waves_per_simd(KM, CAP, THREADS)) void dcd_segment_kernel(
     const uint8_t* __restrict__ lab, const int32_t* __restrict__ labels, int B, int H, int W,
     int nseg, int k, int use_hash, uint32_t seed, float* __restrict__ centres,
     uint8_t* __restrict__ assign, SegState* __restrict__ seg, unsigned long long* __restrict__ stats,
     const int* __restrict__ bbox, int* __restrict__ retry, int* __restrict__ big_count,
-    int max_rounds) {
+    int max_rounds, SegLists L, int tier) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (FIRST) {
-        segment_body<KM, CAP, THREADS, true>(smem, blockIdx.y, blockIdx.x, B, lab, labels, H, W, nseg,
-                                             k, use_hash, seed, centres, assign, seg, stats, bbox,
-                                             retry, big_count, max_rounds);
+    if (MODE == MODE_FIRST) {
+        segment_body<KM, CAP, THREADS, MODE_FIRST>(smem, blockIdx.y, blockIdx.x, B, lab, labels, H, W,
+                                                   nseg, k, use_hash, seed, centres, assign, seg,
+                                                   stats, bbox, retry, big_count, max_rounds, L);
+    } else if (MODE == MODE_LISTED) {
+        // the workgroups draw tickets for the entries of their tier's list: segments differ in
+        // size and in rounds by an order of magnitude, so a fixed split would leave a long tail
+        int* ticket = reinterpret_cast<int*>(smem + seg_lds_bytes(KM, CAP) - 8);
+        const int count = L.hdr[tier];
+        while (true) {
+            if (threadIdx.x == 0) *ticket = atomicAdd(&L.hdr[4 + tier], 1);
+            __syncthreads();
+            const int e = *ticket;
+            __syncthreads();
+            if (e >= count) break;
+            const int gs = L.tier[tier][e];
+            segment_body<KM, CAP, THREADS, MODE_LISTED>(smem, gs / nseg, gs % nseg, B, lab, labels, H,
+                                                        W, nseg, k, use_hash, seed, centres, assign,
+                                                        seg, stats, bbox, retry, big_count,
+                                                        max_rounds, L);
+            __syncthreads();
+        }
     } else {
         // a fixed, small grid walks the retry list (launching one workgroup per segment just to
         // find most of them done cost more than the segments that needed the retry)
         const int count = retry[0];
         for (int e = blockIdx.x; e < count; e += gridDim.x) {
             const int gs = retry[1 + e];
-            segment_body<KM, CAP, THREADS, false>(smem, gs / nseg, gs % nseg, B, lab, labels, H, W,
-                                                  nseg, k, use_hash, seed, centres, assign, seg,
-                                                  stats, bbox, retry, big_count, max_rounds);
+            segment_body<KM, CAP, THREADS, MODE_RETRY>(smem, gs / nseg, gs % nseg, B, lab, labels, H,
+                                                       W, nseg, k, use_hash, seed, centres, assign,
+                                                       seg, stats, bbox, retry, big_count,
+                                                       max_rounds, L);
             __syncthreads();
         }
     }
 }
 
-size_t seg_lds_bytes(int km, int cap) {
-    const int accw = (cap / 64) * 255 < 65536 ? 3 : 4;
-    return (size_t)cap * 6 + (size_t)km * accw * 64 * 4 + (size_t)km * 8 + (size_t)km * 3 * 4 * 2 +
-           (size_t)km * 4 * 4 + (size_t)km * 3 * 4 + 16;
-}
-
-template <int KM, int CAP, int THREADS, bool FIRST>
+template <int KM, int CAP, int THREADS, int MODE>
 int launch_tier(dim3 grid, hipStream_t st, const uint8_t* lab, const int32_t* labels, int B, int H,
                 int W, int nseg, int k, int use_hash, uint32_t seed, float* centres, uint8_t* assign,
                 SegState* seg, unsigned long long* stats, const int* bbox, int* retry, int* n_big,
-                int max_rounds) {
+                int max_rounds, const SegLists& L, int tier) {
     size_t lds = seg_lds_bytes(KM, CAP);
-    auto fn = dcd_segment_kernel<KM, CAP, THREADS, FIRST>;
+    auto fn = dcd_segment_kernel<KM, CAP, THREADS, MODE>;
     IMGAN_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
     hipLaunchKernelGGL(fn, grid, dim3(THREADS), lds, st, lab, labels, B, H, W, nseg, k, use_hash, seed,
-                       centres, assign, seg, stats, bbox, retry, n_big, max_rounds);
+                       centres, assign, seg, stats, bbox, retry, n_big, max_rounds, L, tier);
     return 0;
 }
 
@@ -882,20 +1215,97 @@ static int dcd_segments(const uint8_t* lab, const int32_t* labels, int B, int H,
     dim3 gs((unsigned)nseg, (unsigned)B);
     dim3 gr((unsigned)std::min<size_t>(nsegs, 2048));
     unsigned long long* stt = (unsigned long long*)stats;
-#define TIER(KM, CAP, THR, FIRST)                                                                   \
-    if (int rc = launch_tier<KM, CAP, THR, FIRST>(FIRST ? gs : gr, st, lab, labels, B, H, W, nseg, k, \
-                                                  use_hash_init, seed, centres, assign, seg, stt,    \
-                                                  bbox, retry, n_big_out, max_rounds))               \
+    SegLists none = {};
+#define TIER(KM, CAP, THR, MODE)                                                                     \
+    if (int rc = launch_tier<KM, CAP, THR, MODE>(MODE == MODE_FIRST ? gs : gr, st, lab, labels, B, H, \
+                                                 W, nseg, k, use_hash_init, seed, centres, assign,   \
+                                                 seg, stt, bbox, retry, n_big_out, max_rounds, none, \
+                                                 0))                                                 \
         return rc;
     if (k <= 8) {
-        TIER(8, CAP_SMALL, THREADS_SMALL, true)
-        TIER(8, CAP_LARGE, THREADS_LARGE, false)
+        TIER(8, CAP_SMALL, THREADS_SMALL, MODE_FIRST)
+        TIER(8, CAP_LARGE, THREADS_LARGE, MODE_RETRY)
     } else {
-        TIER(16, CAP_SMALL_K16, THREADS_SMALL, true)
-        TIER(16, CAP_LARGE, THREADS_LARGE, false)
+        TIER(16, CAP_SMALL_K16, THREADS_SMALL, MODE_FIRST)
+        TIER(16, CAP_LARGE, THREADS_LARGE, MODE_RETRY)
     }
 #undef TIER
     return imgan::check_launch("imgan_dcd_segments");
+}
+
+extern "C" size_t imgan_dcd_list_bytes(int B, int H, int W, int nseg) {
+    if (B < 1 || H < 1 || W < 1 || nseg < 1) return 0;
+    return seg_lists_bytes((size_t)B * nseg, (size_t)B * H * W);
+}
+
+extern "C" int imgan_label_counts(const int32_t* labels, int B, int H, int W, int nseg,
+                                  int32_t* counts, imgan_stream_t stream) {
+    IMGAN_REQUIRE(labels && counts, "imgan_label_counts: null pointer");
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535 && H <= 65535 * SC_ROWS,
+                  "imgan_label_counts: bad shape");
+    IMGAN_REQUIRE((long long)H * W < 0x7fffffffLL, "imgan_label_counts: image too large");
+    hipStream_t st = (hipStream_t)stream;
+    IMGAN_HIP(hipMemsetAsync(counts, 0, (size_t)B * nseg * 4, st));
+    dim3 grid((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, SC_ROWS), (unsigned)B);
+    SegLists none = {};
+    hipLaunchKernelGGL(seg_scatter_kernel<true>, grid, dim3(256), 0, st, (const uint8_t*)nullptr,
+                       labels, B, H, W, nseg, none, counts);
+    return imgan::check_launch("seg_scatter_kernel<count>");
+}
+
+extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labels, int B, int H,
+                                         int W, int nseg, int k, int use_hash_init, uint32_t seed,
+                                         float* centres, uint8_t* assign, void* state,
+                                         uint64_t* stats, const int32_t* bbox, const int32_t* counts,
+                                         void* list_scratch, int32_t* n_big_out, int max_rounds,
+                                         imgan_stream_t stream) {
+    IMGAN_REQUIRE(lab && labels && centres && assign && state && stats && bbox && counts &&
+                      list_scratch && n_big_out,
+                  "imgan_dcd_segments_listed: null pointer");
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535 && H <= 65535 && W <= 65536,
+                  "imgan_dcd_segments_listed: bad shape");
+    IMGAN_REQUIRE(k >= 1 && k <= KMAX, "imgan_dcd_segments_listed: 1 <= k <= 16 dominant colours");
+    IMGAN_REQUIRE((long long)H * W < 0x7fffffffLL && (long long)B * H * W < 0xffffffffLL &&
+                      (long long)B * nseg < 0x7fffffffLL,
+                  "imgan_dcd_segments_listed: batch too large");
+    IMGAN_REQUIRE((long long)B * H * W >= 2, "imgan_dcd_segments_listed: needs at least two pixels");
+    IMGAN_REQUIRE(max_rounds >= 1, "imgan_dcd_segments_listed: max_rounds must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    DcdLayout D = dcd_layout(B, nseg, k);
+    SegState* seg = (SegState*)((char*)state + D.off_seg);
+    const size_t nsegs = (size_t)B * nseg, npx = (size_t)B * H * W;
+    SegLists L = bind_lists(list_scratch, nsegs, npx);
+    IMGAN_HIP(hipMemsetAsync(state, 0, D.total, st));
+    IMGAN_HIP(hipMemsetAsync(n_big_out, 0, 4, st));
+    IMGAN_HIP(hipMemsetAsync(assign, 0xff, npx, st));
+    const int cap0 = k <= 8 ? CAP_TINY : 0;
+    const int cap1 = k <= 8 ? CAP_SMALL : CAP_SMALL_K16;
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(1024), 0, st, counts, bbox, (int)nsegs, H, W,
+                       (unsigned long long)npx, L, cap0, cap1, CAP_LARGE, n_big_out);
+    dim3 gsc((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, SC_ROWS), (unsigned)B);
+    hipLaunchKernelGGL(seg_scatter_kernel<false>, gsc, dim3(256), 0, st, lab, labels, B, H, W, nseg, L,
+                       (int32_t*)nullptr);
+    unsigned long long* stt = (unsigned long long*)stats;
+    // The large tier first (its few long jobs should not be what everything else waits for at the
+    // end); a grid of a few workgroups per CU slot, which draw segments until the tier's list is
+    // empty.  (Measured: the tiers on three streams side by side gain 2 % at 64 images and lose
+    // 1 % at 256; they stay on the caller's stream.)
+#define TIER(KM, CAP, THR, PER_CU, T)                                                                 \
+    if (int rc = launch_tier<KM, CAP, THR, MODE_LISTED>(                                              \
+            dim3((unsigned)std::min<size_t>(nsegs, 256 * PER_CU)), st, lab, labels, B, H, W, nseg, k, \
+            use_hash_init, seed, centres, assign, seg, stt, bbox, nullptr, n_big_out, max_rounds, L,  \
+            T))                                                                                       \
+        return rc;
+    if (k <= 8) {
+        TIER(8, CAP_LARGE, THREADS_LARGE, 1, 2)
+        TIER(8, CAP_SMALL, THREADS_SMALL, 2, 1)
+        TIER(8, CAP_TINY, THREADS_TINY, 3, 0)
+    } else {
+        TIER(16, CAP_LARGE, THREADS_LARGE, 1, 2)
+        TIER(16, CAP_SMALL_K16, THREADS_SMALL, 2, 1)
+    }
+#undef TIER
+    return imgan::check_launch("imgan_dcd_segments_listed");
 }
 
 extern "C" int imgan_dcd_segments(const uint8_t* lab, const int32_t* labels, int B, int H, int W,

@@ -952,6 +952,11 @@ __global__ void slic_finalise_kernel(int32_t* __restrict__ centres, Ws w, int B,
     for (int k = 0; k < 5; ++k) o[k] = cnt ? (int32_t)(s[k] / cnt) : 0;
 }
 
+__global__ void slic_counts_kernel(int32_t* __restrict__ counts, Ws w, int total) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) counts[t] = (int32_t)w.sums[(size_t)t * NFIELD + 5];
+}
+
 // 0: 32-bit key, 1: u64 key, 2: literal float64 (non-integral colour weight).  *rel: the
 // 32-bit key also fits a signed word once its per-pixel constant is dropped.
 int key_mode(int S, double cw, bool* rel) {
@@ -1182,6 +1187,16 @@ extern "C" int imgan_slic_finalise_centres(int32_t* centres, int B, int H, int W
     hipLaunchKernelGGL(slic_finalise_kernel, dim3(imgan::cdiv(B * n, 256)), dim3(256), 0,
                        (hipStream_t)stream, centres, w, B, n);
     return imgan::check_launch("slic_finalise_kernel");
+}
+
+extern "C" int imgan_slic_label_counts(int B, int H, int W, int S, int n, const void* workspace,
+                                       int32_t* counts, imgan_stream_t stream) {
+    IMGAN_REQUIRE(counts && workspace, "imgan_slic_label_counts: null pointer");
+    if (int rc = validate("imgan_slic_label_counts", B, H, W, S, n)) return rc;
+    Ws w = bind(const_cast<void*>(workspace), make_layout(B, H, W, S, n));
+    hipLaunchKernelGGL(slic_counts_kernel, dim3(imgan::cdiv(B * n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, counts, w, B * n);
+    return imgan::check_launch("slic_counts_kernel");
 }
 
 extern "C" int imgan_slic_run(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,

@@ -42,6 +42,8 @@ SIGNATURES = {
                                                    c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "imgan_slic_finalise_centres": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                             c_void_p]),
+    "imgan_slic_label_counts": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p]),
     "imgan_slic_run": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "imgan_rag_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
@@ -72,6 +74,11 @@ SIGNATURES = {
     "imgan_dcd_segments_boxed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                          ctypes.c_uint32, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_int, c_void_p]),
+    "imgan_dcd_list_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "imgan_dcd_segments_listed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          ctypes.c_uint32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "imgan_label_counts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "imgan_dcd_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "imgan_dcd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -176,6 +176,14 @@ class SlicPlan(object):
         check(lib.imgan_slic_finalise_centres(_ptr(self.centres), *a, _ptr(self.workspace),
                                               _stream()))
 
+    def label_counts(self, out=None):
+        """int32 [B,n]: pixels per label after the last round (valid until the next round())."""
+        if out is None:
+            out = torch.empty((self.B, self.n), dtype=torch.int32, device=self.device)
+        check(lib.imgan_slic_label_counts(self.B, self.H, self.W, self.S, self.n,
+                                          _ptr(self.workspace), _ptr(out), _stream()))
+        return out
+
     def run(self, lab, colour_weight, num_iter):
         """SLICSuperPixel.run() (slic.py:78-127); returns (labels, centres) device tensors."""
         lab = self._check(lab)
@@ -435,10 +443,19 @@ class DcdPlan(object):
     (merged regions) continue through the streaming rounds and the whole-image component
     labelling.  Both give the same numbers."""
 
-    def __init__(self, B, H, W, nseg, k):
+    def __init__(self, B, H, W, nseg, k, lists=True):
+        """lists: sort the pixels by segment first (imgan_dcd_segments_listed; 8 bytes of
+        scratch per pixel) instead of letting every segment scan its bounding box."""
         _require_gpu()
         self.B, self.H, self.W, self.nseg, self.k = int(B), int(H), int(W), int(nseg), int(k)
         dev = torch.device("cuda", torch.cuda.current_device())
+        self.lists = bool(lists) and self.W <= 65536 and self.B * self.H * self.W < 2 ** 32
+        self.list_scratch = self.counts = None
+        if self.lists:
+            self.list_scratch = torch.empty(
+                lib.imgan_dcd_list_bytes(self.B, self.H, self.W, self.nseg), dtype=torch.uint8,
+                device=dev)
+            self.counts = torch.empty((self.B, self.nseg), dtype=torch.int32, device=dev)
         self.state = torch.zeros(lib.imgan_dcd_state_bytes(self.B, self.nseg, self.k),
                                  dtype=torch.uint8, device=dev)
         self.assign = torch.empty((self.B, self.H, self.W), dtype=torch.uint8, device=dev)
@@ -456,12 +473,14 @@ class DcdPlan(object):
     LDS_CAPACITY = 22528
 
     def kmeans(self, lab, labels, centres, seed=None, max_rounds=1000, check_every=1,
-               streaming_only=False, boxed=False, max_segment_px=None):
+               streaming_only=False, boxed=False, max_segment_px=None, counted=False):
         """Runs every segment's Lloyd loop to the reference's stop rule.
         centres: float32 [B,nseg,k,3], updated in place; with seed is not None they are
         sampled on the device (hash rule of imgan_dcd_init_hash), otherwise they must hold
         the initial centres.  boxed: self.bbox already holds the bounding boxes of `labels`
         (SlicPlan.round(..., bbox=self.bbox) on the round that made them).
+        counted: self.counts already holds the pixel count of every segment
+        (SlicPlan.label_counts(out=self.counts)); counted otherwise (plans with lists only).
         max_segment_px: an upper bound on the pixels of any segment that the caller can prove (a
         SLIC superpixel lies inside its centre's 2S x 2S window, slic.py:94-100); when it is within
         the on-chip capacity no segment can be left for the streaming rounds, so the count of
@@ -482,10 +501,23 @@ class DcdPlan(object):
             self.big_segments = self.B * self.nseg
             state_for_skip = None
         else:
-            fn = lib.imgan_dcd_segments_boxed if boxed else lib.imgan_dcd_segments
-            check(fn(_ptr(lab), _ptr(labels), *shape, 1 if use_hash else 0, cseed, _ptr(centres),
-                     _ptr(self.assign), _ptr(self.state), _ptr(self.stats), _ptr(self.bbox),
-                     _ptr(self.n_big), int(max_rounds), _stream()))
+            if self.lists:
+                if not boxed:
+                    check(lib.imgan_label_bbox(_ptr(labels), self.B, self.H, self.W, self.nseg,
+                                               _ptr(self.bbox), _stream()))
+                if not counted:
+                    check(lib.imgan_label_counts(_ptr(labels), self.B, self.H, self.W, self.nseg,
+                                                 _ptr(self.counts), _stream()))
+                check(lib.imgan_dcd_segments_listed(
+                    _ptr(lab), _ptr(labels), *shape, 1 if use_hash else 0, cseed, _ptr(centres),
+                    _ptr(self.assign), _ptr(self.state), _ptr(self.stats), _ptr(self.bbox),
+                    _ptr(self.counts), _ptr(self.list_scratch), _ptr(self.n_big), int(max_rounds),
+                    _stream()))
+            else:
+                fn = lib.imgan_dcd_segments_boxed if boxed else lib.imgan_dcd_segments
+                check(fn(_ptr(lab), _ptr(labels), *shape, 1 if use_hash else 0, cseed,
+                         _ptr(centres), _ptr(self.assign), _ptr(self.state), _ptr(self.stats),
+                         _ptr(self.bbox), _ptr(self.n_big), int(max_rounds), _stream()))
             if max_segment_px is not None and int(max_segment_px) <= self.LDS_CAPACITY:
                 self.big_segments = 0
             else:
@@ -574,6 +606,18 @@ class DescriptorPlan(object):
         check(lib.imgan_csd(_ptr(bgr), self.B, self.H, self.W, self.nbins, _ptr(self.csd),
                             _stream()))
         return self.csd
+
+
+def label_counts(labels, nseg):
+    """int32 [B,nseg]: pixels per label (labels outside [0, nseg) are skipped)."""
+    _require_gpu()
+    if labels.dim() == 2:
+        labels = labels.unsqueeze(0)
+    _dev(labels, torch.int32, "labels")
+    B, H, W = labels.shape
+    counts = torch.empty((B, int(nseg)), dtype=torch.int32, device=labels.device)
+    check(lib.imgan_label_counts(_ptr(labels), B, H, W, int(nseg), _ptr(counts), _stream()))
+    return counts
 
 
 def label_bbox(labels, nseg):

@@ -64,6 +64,9 @@ class FullPipeline(object):
             else:
                 self.slic.round(self.lab, self.cw, bbox=box, first=(it == 1))
         self.boxed = self.dcd is not None and self.num_iter > 1
+        if self.boxed and self.dcd.lists:
+            # ... and the pixel count of every superpixel (the divisor of its centre update)
+            self.slic.label_counts(out=self.dcd.counts)
         return self.slic.labels
 
     def run_dcd(self, timed=False):
@@ -75,6 +78,7 @@ class FullPipeline(object):
             self._timed("dcd_segments", timed, lambda: self.dcd.kmeans(
                 self.lab, labels, self.centres, seed=self.seed, max_rounds=self.max_rounds,
                 check_every=self.check_every, boxed=getattr(self, "boxed", False),
+                counted=getattr(self, "boxed", False) and self.dcd.lists,
                 max_segment_px=(2 * self.slic.S) ** 2))
             self.dcd_rounds_run = self.dcd.rounds_run
             stats = self.dcd.statistics(self.lab, labels)

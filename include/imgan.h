@@ -113,6 +113,12 @@ int imgan_slic_assign_accumulate_first(const uint8_t* lab, int32_t* labels, int 
 int imgan_slic_finalise_centres(int32_t* centres, int B, int H, int W, int S, int n,
                                 void* workspace, imgan_stream_t stream);
 
+/* counts int32 [B][n]: the pixels that carry each label after the last
+ * imgan_slic_assign_accumulate* call (the divisor of slic.py:125), valid until the next
+ * imgan_slic_bin_centres clears the sums.  What imgan_dcd_segments_listed wants to know. */
+int imgan_slic_label_counts(int B, int H, int W, int S, int n, const void* workspace,
+                            int32_t* counts, imgan_stream_t stream);
+
 /* SLICSuperPixel.run(), slic.py:78-127: init + (num_iter-1) x (bin, assign, finalise). */
 int imgan_slic_run(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,
                    double colour_weight, int num_iter, int32_t* centres, int32_t* labels,
@@ -247,6 +253,26 @@ int imgan_dcd_segments_boxed(const uint8_t* lab, const int32_t* labels, int B, i
                              int nseg, int k, int use_hash_init, uint32_t seed, float* centres,
                              uint8_t* assign, void* state, uint64_t* stats, void* bbox_scratch,
                              int32_t* n_big_out, int max_rounds, imgan_stream_t stream);
+
+/* The same with bounding boxes AND pixel counts known (bbox int32 [B][nseg][4], counts int32
+ * [B][nseg]; imgan_label_bbox / imgan_label_counts, or the last SLIC round and
+ * imgan_slic_label_counts): one streaming pass sorts the pixels by segment into list_scratch
+ * (imgan_dcd_list_bytes() bytes, 8 per pixel), every segment's workgroup then reads its own
+ * run instead of scanning its bounding box, and goes straight to the LDS tier that fits it
+ * (np.where(clusters == seg) of mpeg7Descriptors.py:28-33 for all segments in one pass).
+ * Same results as imgan_dcd_segments.  Needs W <= 65536 and B*H*W < 2^32.  Counts that
+ * disagree with `labels` lose the surplus pixels (never memory safety). */
+size_t imgan_dcd_list_bytes(int B, int H, int W, int nseg);
+int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
+                              int nseg, int k, int use_hash_init, uint32_t seed, float* centres,
+                              uint8_t* assign, void* state, uint64_t* stats, const int32_t* bbox,
+                              const int32_t* counts, void* list_scratch, int32_t* n_big_out,
+                              int max_rounds, imgan_stream_t stream);
+
+/* counts int32 [B][nseg]: pixels per label (labels outside [0, nseg) are skipped); the
+ * np.where(clusters == seg) sizes of mpeg7Descriptors.py:28-33 for every segment at once. */
+int imgan_label_counts(const int32_t* labels, int B, int H, int W, int nseg, int32_t* counts,
+                       imgan_stream_t stream);
 
 /* mpeg7Descriptors.py:114-129 from the integer statistics: features float32 [B][nseg][k][8] =
  * mean(3), population variance(3), percentage, spatial coherence (16-byte aligned). */

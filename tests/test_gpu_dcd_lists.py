@@ -1,0 +1,169 @@
+"""The pixel-list front end of the dominant-colour kernel (imgan_dcd_segments_listed) against the
+bounding-box gather it replaces (imgan_dcd_segments / _boxed): same arithmetic on the same pixels,
+so centres, assignment, statistics and round counts must be identical (bit-exact), whichever
+capacity tier a segment lands in.  The gather path itself is pinned to the oracle in
+test_gpu_descriptors.py / test_gpu_fullsize_oracle.py."""
+import numpy as np
+import pytest
+
+from conftest import voronoi_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch
+
+
+def _run(ops, torch, lab, dl, nseg, k, lists, cen0=None, seed=None, **kw):
+    B, H, W = dl.shape
+    plan = ops.DcdPlan(B, H, W, nseg, k, lists=lists)
+    assert plan.lists == lists
+    if cen0 is None:
+        cen = torch.zeros((B, nseg, k, 3), dtype=torch.float32, device="cuda")
+    else:
+        cen = torch.from_numpy(cen0.copy()).cuda()
+    plan.kmeans(lab, dl, cen, seed=seed, **kw)
+    stats = plan.statistics(lab, dl)
+    rounds, done = plan.rounds()
+    torch.cuda.synchronize()
+    return (cen.cpu().numpy(), plan.assign.cpu().numpy().copy(), stats.cpu().numpy().copy(),
+            rounds.cpu().numpy(), done.cpu().numpy(), plan.big_segments)
+
+
+def _same(a, b):
+    assert a[5] == b[5]
+    for i in range(5):
+        assert np.array_equal(a[i], b[i]), i
+
+
+def test_label_counts_match_bincount():
+    torch = _torch()
+    from imgan import ops
+    rng = np.random.RandomState(3)
+    for (B, H, W, nseg) in [(1, 1, 1, 1), (2, 37, 301, 11), (1, 129, 517, 700), (3, 64, 64, 5)]:
+        labels = rng.randint(-2, nseg + 3, size=(B, H, W)).astype(np.int32)
+        if nseg == 700:                       # every pixel its own run: more labels per block
+            labels = rng.randint(0, nseg, size=(B, H, W)).astype(np.int32)   # than table slots
+        got = ops.label_counts(torch.from_numpy(labels).cuda(), nseg).cpu().numpy()
+        for b in range(B):
+            l = labels[b].ravel()
+            want = np.bincount(l[(l >= 0) & (l < nseg)], minlength=nseg)
+            assert np.array_equal(got[b], want), (B, H, W, nseg, b)
+
+
+def test_slic_label_counts_are_the_counts_of_the_label_map():
+    torch = _torch()
+    from imgan import ops
+    from oracle.color import bgr2lab_u8
+    img = voronoi_image(150, 230, 40, seed=5, noise=12.0)
+    lab = torch.from_numpy(bgr2lab_u8(img)).cuda().unsqueeze(0)
+    plan = ops.SlicPlan(1, 150, 230, 60)
+    plan.seed(lab)
+    for it in range(3):
+        plan.round(lab, 20.0, first=(it == 0))
+        labels = plan.labels.cpu().numpy().ravel()
+        want = np.bincount(labels[labels >= 0], minlength=plan.n)
+        assert np.array_equal(plan.label_counts().cpu().numpy()[0], want), it
+
+
+@pytest.mark.parametrize("k", [3, 8, 12])
+def test_listed_equals_gather_on_superpixels(k):
+    """SLIC superpixels of two images (all three tiers for k <= 8: small, medium and a few large
+    segments), hash-sampled initial centres."""
+    torch = _torch()
+    from imgan import ops
+    from oracle.color import bgr2lab_u8
+    H, W = 360, 500
+    imgs = np.stack([voronoi_image(H, W, 50, seed=7 + i, noise=14.0) for i in range(2)])
+    lab = torch.from_numpy(np.stack([bgr2lab_u8(im) for im in imgs])).cuda()
+    # 30 clusters -> S = 77, superpixels of ~9000 px: the tiers 7680 / 12288 / 22528 all get some
+    slic = ops.SlicPlan(2, H, W, 30)
+    slic.run(lab, 20.0, 4)
+    dl = slic.labels
+    a = _run(ops, torch, lab, dl, slic.n, k, False, seed=99)
+    b = _run(ops, torch, lab, dl, slic.n, k, True, seed=99)
+    _same(a, b)
+    first = dl[0].cpu().numpy().ravel()
+    sizes = np.bincount(first[first >= 0])
+    assert (sizes <= 7680).any() and ((sizes > 7680) & (sizes <= 22528)).any(), sizes
+
+
+def test_listed_equals_gather_edge_cases():
+    """Empty segment ids, unlabelled pixels, a segment beyond the on-chip capacity (left to the
+    streaming rounds by both), a one-pixel segment, a segment whose box is too large for its tier,
+    given initial centres."""
+    torch = _torch()
+    from imgan import ops
+    from oracle.color import bgr2lab_u8
+    H, W = 220, 300
+    k = 4
+    img = voronoi_image(H, W, 20, seed=17, noise=20.0)
+    labf = bgr2lab_u8(img)
+    lab = torch.from_numpy(labf).cuda().unsqueeze(0)
+    labels = np.full((H, W), -1, dtype=np.int32)
+    labels[0:160, 0:200] = 0                       # 32000 px: beyond the largest tier
+    labels[170:172, 0:50] = 1
+    labels[180, 10] = 2                            # one pixel
+    # id 3 stays empty
+    labels[0:200:7, 210:290:5] = 4                 # few pixels scattered over a large box
+    labels[190:220, 100:200] = 5
+    labels[165, :] = 7                             # a thin line across the image; id 6 empty
+    nseg = 9                                       # id 8 empty too
+    dl = torch.from_numpy(labels).cuda().unsqueeze(0)
+    rng = np.random.RandomState(1)
+    cen0 = np.zeros((1, nseg, k, 3), dtype=np.float32)
+    for s in range(nseg):
+        idx = np.nonzero(labels.ravel() == s)[0]
+        if len(idx):
+            cen0[0, s] = labf.reshape(-1, 3)[rng.choice(idx, k, replace=len(idx) < k)]
+    a = _run(ops, torch, lab, dl, nseg, k, False, cen0=cen0)
+    b = _run(ops, torch, lab, dl, nseg, k, True, cen0=cen0)
+    assert a[5] == 1
+    _same(a, b)
+    a = _run(ops, torch, lab, dl, nseg, k, False, seed=5)
+    b = _run(ops, torch, lab, dl, nseg, k, True, seed=5)
+    _same(a, b)
+
+
+def test_listed_with_wrong_counts_stays_in_bounds():
+    """Counts that disagree with the label map (a caller's mistake) lose pixels, not memory
+    safety: the call finishes and the segments whose counts were right are unaffected."""
+    torch = _torch()
+    from imgan import ops
+    from oracle.color import bgr2lab_u8
+    H, W = 120, 160
+    img = voronoi_image(H, W, 12, seed=3, noise=10.0)
+    lab = torch.from_numpy(bgr2lab_u8(img)).cuda().unsqueeze(0)
+    labels = (np.arange(H)[:, None] // 30 * 4 + np.arange(W)[None, :] // 40).astype(np.int32)
+    dl = torch.from_numpy(labels).cuda().unsqueeze(0)
+    nseg, k = 16, 4
+    good = _run(ops, torch, lab, dl, nseg, k, True, seed=8)
+    plan = ops.DcdPlan(1, H, W, nseg, k)
+    ops.label_bbox(dl, nseg)                                      # warm the helper as well
+    plan.bbox[:nseg * 16].copy_(ops.label_bbox(dl, nseg).view(torch.uint8).flatten())
+    counts = ops.label_counts(dl, nseg)
+    counts[0, 3] = 10                      # too small
+    counts[0, 5] = 2000                    # too large
+    counts[0, 9] = -4                      # nonsense
+    plan.counts.copy_(counts)
+    cen = torch.zeros((1, nseg, k, 3), dtype=torch.float32, device="cuda")
+    plan.kmeans(lab, dl, cen, seed=8, boxed=True, counted=True)
+    torch.cuda.synchronize()
+    stats = plan.stats.cpu().numpy()[0]
+    assert stats[3, :, 0].sum() == 10 and stats[9, :, 0].sum() == 0
+    assert stats[5, :, 0].sum() == 30 * 40
+    for s in (0, 1, 2, 15):
+        assert np.array_equal(stats[s], good[2][0, s])
+    # a total beyond the pixel count: the runs behind it are cut short, nothing is written outside
+    counts[0, 12] = 1 << 30
+    plan.counts.copy_(counts)
+    plan.kmeans(lab, dl, cen, seed=8, boxed=True, counted=True)
+    torch.cuda.synchronize()
+    stats = plan.stats.cpu().numpy()[0]
+    for s in (0, 1, 2):
+        assert np.array_equal(stats[s], good[2][0, s])
+    assert stats[:, :, 0].sum() <= H * W
