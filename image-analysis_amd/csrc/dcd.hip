@@ -5,8 +5,8 @@
 // (lowest cluster index wins ties, :87-92); centre = float32(sum) / count (:96-99); stop rule
 // |previous shift sum - shift sum| < 0.1 with the shift summed in float32 per component and
 // the three components added in float64 (:102-107).  Deviations (documented in DESIGN.md):
-// initial centres are injected, an empty cluster keeps its centre, spatial coherence uses
-// true 8-connectivity.
+// initial centres are injected, an empty cluster is re-seeded by a hash rule in place of
+// random.sample (:101, resample_key in dcd_common.h), spatial coherence uses true 8-connectivity.
 //
 // Every segment runs its own loop: a segment that met the stop rule is frozen (its pixels are
 // skipped), so one "round" call advances only the segments still running.
@@ -131,36 +131,18 @@ __global__ __launch_bounds__(256) void dcd_assign_kernel(
     }
 }
 
-// ---- centre update + stop rule (:93-107), one thread per segment
-__global__ void dcd_update_kernel(int nsegs, int k, float* __restrict__ centres,
-                                  SegState* __restrict__ seg, float* __restrict__ oldcen,
-                                  unsigned long long* __restrict__ acc, int* __restrict__ active) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nsegs) return;
-    SegState st = seg[s];
-    if (st.done) return;
-    float* c = centres + (size_t)s * k * 3;
-    float* o = oldcen + (size_t)s * k * 3;
-    unsigned long long* a = acc + (size_t)s * k * 4;
+// ---- centre update + stop rule (:93-107), one thread per segment.  An empty cluster takes its
+// re-sample draw (:101): known from an earlier round, or looked for by the two kernels below, in
+// which case the segment's round is finished there (pending).
+__device__ __forceinline__ void finish_round(SegState& st, int k, const float* c, float* o,
+                                             int* __restrict__ active) {
     float sh0 = 0.f, sh1 = 0.f, sh2 = 0.f;
     for (int j = 0; j < k; ++j) {
-        unsigned long long n = a[4 * j];
-        float c0 = c[3 * j], c1 = c[3 * j + 1], c2 = c[3 * j + 2];
-        if (n) {
-            float fn = (float)n;
-            c0 = __fdiv_rn((float)a[4 * j + 1], fn);
-            c1 = __fdiv_rn((float)a[4 * j + 2], fn);
-            c2 = __fdiv_rn((float)a[4 * j + 3], fn);
-            c[3 * j] = c0;
-            c[3 * j + 1] = c1;
-            c[3 * j + 2] = c2;
-        }
-        sh0 = __fadd_rn(sh0, fabsf(__fsub_rn(c0, o[3 * j])));
-        sh1 = __fadd_rn(sh1, fabsf(__fsub_rn(c1, o[3 * j + 1])));
-        sh2 = __fadd_rn(sh2, fabsf(__fsub_rn(c2, o[3 * j + 2])));
-        a[4 * j] = a[4 * j + 1] = a[4 * j + 2] = a[4 * j + 3] = 0ull;
+        sh0 = __fadd_rn(sh0, fabsf(__fsub_rn(c[3 * j], o[3 * j])));
+        sh1 = __fadd_rn(sh1, fabsf(__fsub_rn(c[3 * j + 1], o[3 * j + 1])));
+        sh2 = __fadd_rn(sh2, fabsf(__fsub_rn(c[3 * j + 2], o[3 * j + 2])));
     }
-    double cent_sum = ((double)sh0 + (double)sh1) + (double)sh2;
+    const double cent_sum = ((double)sh0 + (double)sh1) + (double)sh2;
     st.rounds += 1;
     if (fabs(st.old_sum - cent_sum) < 0.1) {
         st.done = 1;
@@ -169,6 +151,98 @@ __global__ void dcd_update_kernel(int nsegs, int k, float* __restrict__ centres,
         st.old_sum = cent_sum;
         if (active) atomicAdd(active, 1);
     }
+}
+
+__global__ void dcd_update_kernel(int nsegs, int nseg, int k, long long npix,
+                                  const uint8_t* __restrict__ lab, float* __restrict__ centres,
+                                  SegState* __restrict__ seg, float* __restrict__ oldcen,
+                                  unsigned long long* __restrict__ acc,
+                                  unsigned long long* __restrict__ draw, int* __restrict__ wanted,
+                                  int* __restrict__ active) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsegs) return;
+    SegState st = seg[s];
+    if (st.done) return;
+    float* c = centres + (size_t)s * k * 3;
+    float* o = oldcen + (size_t)s * k * 3;
+    unsigned long long* a = acc + (size_t)s * k * 4;
+    unsigned long long* dr = draw + (size_t)s * k;
+    const uint8_t* im = lab + (size_t)(s / nseg) * npix * 3;
+    int pending = 0;
+    for (int j = 0; j < k; ++j) {
+        unsigned long long n = a[4 * j];
+        if (n) {
+            float fn = (float)n;
+            c[3 * j] = __fdiv_rn((float)a[4 * j + 1], fn);
+            c[3 * j + 1] = __fdiv_rn((float)a[4 * j + 2], fn);
+            c[3 * j + 2] = __fdiv_rn((float)a[4 * j + 3], fn);
+        } else if (dr[j] > DRAW_WANTED) {                 // drawn in an earlier round
+            const uint8_t* q = im + (size_t)(uint32_t)(~dr[j]) * 3;
+            c[3 * j] = (float)q[0];
+            c[3 * j + 1] = (float)q[1];
+            c[3 * j + 2] = (float)q[2];
+        } else {
+            dr[j] = DRAW_WANTED;
+            pending |= 1 << j;
+        }
+        a[4 * j] = a[4 * j + 1] = a[4 * j + 2] = a[4 * j + 3] = 0ull;
+    }
+    st.pending = pending;
+    if (pending)
+        atomicAdd(wanted, 1);
+    else
+        finish_round(st, k, c, o, active);
+    seg[s] = st;
+}
+
+// the draws asked for in this round: every pixel of a pending segment bids for its clusters
+__global__ __launch_bounds__(256) void dcd_draw_kernel(const int32_t* __restrict__ labels,
+                                                       long long npix, int nseg, int k, uint32_t seed,
+                                                       const SegState* __restrict__ seg,
+                                                       unsigned long long* __restrict__ draw,
+                                                       const int* __restrict__ wanted) {
+    if (*wanted == 0) return;
+    const int b = blockIdx.y;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < npix;
+         p += (long long)gridDim.x * 256) {
+        const int s = labels[(size_t)b * npix + p];
+        if (s < 0 || s >= nseg) continue;
+        const size_t gs = (size_t)b * nseg + s;
+        const int pending = seg[gs].done ? 0 : seg[gs].pending;
+        for (int j = 0; j < k; ++j)
+            if ((pending >> j) & 1) {
+                const unsigned long long bid = ~resample_key((uint32_t)p, seed, j);
+                unsigned long long* slot = draw + gs * k + j;
+                // the slot only ever grows: a stale read just costs an extra atomic
+                if (bid > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, bid);
+            }
+    }
+}
+
+__global__ void dcd_draw_apply_kernel(int nsegs, int nseg, int k, long long npix,
+                                      const uint8_t* __restrict__ lab, float* __restrict__ centres,
+                                      SegState* __restrict__ seg, float* __restrict__ oldcen,
+                                      const unsigned long long* __restrict__ draw,
+                                      const int* __restrict__ wanted, int* __restrict__ active) {
+    if (*wanted == 0) return;
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsegs) return;
+    SegState st = seg[s];
+    if (st.done || !st.pending) return;
+    float* c = centres + (size_t)s * k * 3;
+    const uint8_t* im = lab + (size_t)(s / nseg) * npix * 3;
+    for (int j = 0; j < k; ++j)
+        if ((st.pending >> j) & 1) {
+            const unsigned long long d = draw[(size_t)s * k + j];
+            if (d > DRAW_WANTED) {                        // else: a segment without pixels
+                const uint8_t* q = im + (size_t)(uint32_t)(~d) * 3;
+                c[3 * j] = (float)q[0];
+                c[3 * j + 1] = (float)q[1];
+                c[3 * j + 2] = (float)q[2];
+            }
+        }
+    st.pending = 0;
+    finish_round(st, k, c, oldcen + (size_t)s * k * 3, active);
     seg[s] = st;
 }
 
@@ -336,9 +410,9 @@ extern "C" size_t imgan_dcd_state_bytes(int B, int nseg, int k) {
 }
 
 extern "C" int imgan_dcd_kmeans_round(const uint8_t* lab, const int32_t* labels, int B, int H,
-                                      int W, int nseg, int k, float* centres, uint8_t* assign,
-                                      void* state, int first_round, int32_t* active_out,
-                                      imgan_stream_t stream) {
+                                      int W, int nseg, int k, uint32_t seed, float* centres,
+                                      uint8_t* assign, void* state, int first_round,
+                                      int32_t* active_out, imgan_stream_t stream) {
     IMGAN_REQUIRE(lab && labels && centres && assign && state, "imgan_dcd_kmeans_round: null pointer");
     IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535,
                   "imgan_dcd_kmeans_round: bad shape");
@@ -349,15 +423,26 @@ extern "C" int imgan_dcd_kmeans_round(const uint8_t* lab, const int32_t* labels,
     SegState* seg = (SegState*)(base + L.off_seg);
     float* oldcen = (float*)(base + L.off_oldcen);
     unsigned long long* acc = (unsigned long long*)(base + L.off_acc);
+    unsigned long long* draw = (unsigned long long*)(base + L.off_draw);
+    int* wanted = (int*)(base + L.off_wanted);
     hipStream_t st = (hipStream_t)stream;
     long long npix = (long long)H * W;
+    IMGAN_REQUIRE(npix < 0x7fffffffLL, "imgan_dcd_kmeans_round: image too large");
     if (active_out) IMGAN_HIP(hipMemsetAsync(active_out, 0, sizeof(int32_t), st));
+    IMGAN_HIP(hipMemsetAsync(wanted, 0, sizeof(int), st));
     dim3 grid((unsigned)imgan::cdiv(npix, 256 * 8), (unsigned)B);
     hipLaunchKernelGGL(dcd_assign_kernel, grid, dim3(256), 0, st, lab, labels, npix, nseg, k,
                        (const float*)centres, assign, (const SegState*)seg, acc, first_round);
     int nsegs = B * nseg;
-    hipLaunchKernelGGL(dcd_update_kernel, dim3(imgan::cdiv(nsegs, 128)), dim3(128), 0, st, nsegs, k,
-                       centres, seg, oldcen, acc, active_out);
+    hipLaunchKernelGGL(dcd_update_kernel, dim3(imgan::cdiv(nsegs, 128)), dim3(128), 0, st, nsegs, nseg,
+                       k, npix, lab, centres, seg, oldcen, acc, draw, wanted, active_out);
+    // both leave at once unless the update met a cluster that is empty for the first time
+    dim3 gd((unsigned)std::min<long long>(imgan::cdiv(npix, 256), 8192), (unsigned)B);
+    hipLaunchKernelGGL(dcd_draw_kernel, gd, dim3(256), 0, st, labels, npix, nseg, k, seed,
+                       (const SegState*)seg, draw, (const int*)wanted);
+    hipLaunchKernelGGL(dcd_draw_apply_kernel, dim3(imgan::cdiv(nsegs, 128)), dim3(128), 0, st, nsegs,
+                       nseg, k, npix, lab, centres, seg, oldcen, (const unsigned long long*)draw,
+                       (const int*)wanted, active_out);
     return imgan::check_launch("imgan_dcd_kmeans_round");
 }
 

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(1024) void seg_plan_kernel(const int32_t* __restric
 // labels of a block are tallied in a small LDS table (one LDS atomic per run of equal labels in a
 // wave row, which also ranks the pixels of the run); then one global atomic per label and block
 // reserves the block's share of the segment's run, and the pixels are written behind it.
-constexpr int SC_ROWS = 8, SC_SLOTS = 128;
+constexpr int SC_ROWS = 8, SC_SLOTS = 128;         // 4 and 16 rows measured: 0.78 / 0.60 ms where 8 takes 0.54
 
 struct ScatterTable {
     int key[SC_SLOTS];
@@ -461,6 +461,49 @@ __device__ __forceinline__ void unite16(uint16_t* par, uint32_t a, uint32_t b) {
     }
 }
 
+// mpeg7Descriptors.py:101 for the clusters in `empty` (a wave-uniform mask), by one whole wave while
+// the others wait at the round's barrier: rare (a cluster only runs empty when sampled colours
+// coincide or a cluster is crowded out).  Kept out of line on purpose: inlined into the fold, the
+// 16-cluster kernels built by ROCm 7.2 never leave the pixel loop below (the same loop as a
+// callee, and with a constant bound inlined, run fine; the ISA reads correct -- cause not found),
+// and the call costs 1 % of the stage.
+// Writes the drawn pixel's colour to cen[j], cen[stride + j], cen[2 * stride + j].
+__device__ __noinline__ void resample_empty(unsigned long long empty, const uint32_t* pix,
+                                            const uint16_t* pos, int n, int bw, int xmin, int ymin,
+                                            int W, uint32_t seed, float* cen, int stride) {
+    const int lane = threadIdx.x & 63;
+    while (empty) {
+        const int j = __ffsll((long long)empty) - 1;
+        empty &= empty - 1;
+        unsigned long long best = ~0ull;
+        uint32_t colour = 0;
+        for (int i = lane; i < n; i += 64) {
+            const int o = pos[i], yy = o / bw, xx = o - yy * bw;
+            const unsigned long long key =
+                resample_key((uint32_t)((ymin + yy) * W + xmin + xx), seed, j);
+            if (key < best) {
+                best = key;
+                colour = pix[i] & 0xffffffu;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o);
+            const uint32_t other_colour = (uint32_t)__shfl_xor((int)colour, o);
+            if (other < best) {
+                best = other;
+                colour = other_colour;
+            }
+        }
+        if (lane == 0 && best != ~0ull) {
+            cen[j] = (float)(colour & 255u);
+            cen[stride + j] = (float)((colour >> 8) & 255u);
+            cen[2 * stride + j] = (float)((colour >> 16) & 255u);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // One segment, start to finish, by the whole workgroup.  MODE_FIRST: the small tier visits every
 // segment, gathers its pixels from its bounding box and puts those that do not fit on the retry
 // list; MODE_RETRY: the large tier works through that list and counts what is still too large
@@ -511,7 +554,7 @@ __device__ __forceinline__ void segment_body(
     st.done = 1;
     st.rounds = 0;
     st.handled = 1;
-    st.pad = 0;
+    st.pending = 0;
     unsigned long long* out = stats + gs * k * 8;
     uint32_t run_at = 0, run_n = 0;
     if (MODE == MODE_LISTED) {
@@ -815,6 +858,8 @@ __device__ __forceinline__ void segment_body(
             }
             SEG_MARK(3)
             // centre update + stop rule (:93-107); lane j < k holds centre j and its previous value
+            const unsigned long long empty = __ballot(lane < k && nj == 0);
+            if (empty) resample_empty(empty, pix, pos, n, bw, xmin, ymin, W, seed, cen, KM);
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             if (lane < k) {
                 red[lane * 4] = nj;                       // the final statistics read these back
@@ -829,6 +874,10 @@ __device__ __forceinline__ void segment_body(
                     cen[lane] = wc0;
                     cen[KM + lane] = wc1;
                     cen[2 * KM + lane] = wc2;
+                } else {                                  // the re-sampled pixel (:101)
+                    wc0 = cen[lane];
+                    wc1 = cen[KM + lane];
+                    wc2 = cen[2 * KM + lane];
                 }
                 a0 = fabsf(__fsub_rn(wc0, wo0));
                 a1 = fabsf(__fsub_rn(wc1, wo1));
@@ -889,6 +938,8 @@ __device__ __forceinline__ void segment_body(
             __threadfence_block();          // red is read back by other lanes of this wave
             SEG_MARK(3)
             // centre update + stop rule (:93-107)
+            const unsigned long long empty = __ballot(lane < k && red[(lane < k ? lane : 0) * 4] == 0u);
+            if (empty) resample_empty(empty, pix, pos, n, bw, xmin, ymin, W, seed, cen, KM);
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
             if (lane < k) {
                 const uint32_t nj = red[lane * 4];

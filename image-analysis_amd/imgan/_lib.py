@@ -63,7 +63,8 @@ SIGNATURES = {
                                            c_void_p]),
     "imgan_dcd_state_bytes": (c_size_t, [c_int, c_int, c_int]),
     "imgan_dcd_kmeans_round": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                       c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+                                       ctypes.c_uint32, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                       c_void_p]),
     "imgan_dcd_rounds": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_dcd_init_hash": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     ctypes.c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -473,12 +473,16 @@ class DcdPlan(object):
     LDS_CAPACITY = 22528
 
     def kmeans(self, lab, labels, centres, seed=None, max_rounds=1000, check_every=1,
-               streaming_only=False, boxed=False, max_segment_px=None, counted=False):
+               streaming_only=False, boxed=False, max_segment_px=None, counted=False,
+               resample_seed=0):
         """Runs every segment's Lloyd loop to the reference's stop rule.
         centres: float32 [B,nseg,k,3], updated in place; with seed is not None they are
         sampled on the device (hash rule of imgan_dcd_init_hash), otherwise they must hold
         the initial centres.  boxed: self.bbox already holds the bounding boxes of `labels`
         (SlicPlan.round(..., bbox=self.bbox) on the round that made them).
+        resample_seed: drives the re-seeding of clusters that run empty (mpeg7Descriptors.py:101;
+        the rule is stated at imgan_dcd_kmeans_round in imgan.h) when `seed` is None; with a
+        seed the same value serves both.
         counted: self.counts already holds the pixel count of every segment
         (SlicPlan.label_counts(out=self.counts)); counted otherwise (plans with lists only).
         max_segment_px: an upper bound on the pixels of any segment that the caller can prove (a
@@ -493,7 +497,7 @@ class DcdPlan(object):
         if tuple(centres.shape) != (self.B, self.nseg, self.k, 3):
             raise ValueError("centres must be [B,nseg,k,3]")
         use_hash = seed is not None
-        cseed = ctypes.c_uint32(int(seed) & 0xffffffff if use_hash else 0)
+        cseed = ctypes.c_uint32(int(seed if use_hash else resample_seed) & 0xffffffff)
         shape = (self.B, self.H, self.W, self.nseg, self.k)
         state_for_skip = _ptr(self.state)
         if streaming_only:
@@ -533,7 +537,7 @@ class DcdPlan(object):
                                           _ptr(self.slots), state_for_skip, _stream()))
         r = 0
         while r < max_rounds:
-            check(lib.imgan_dcd_kmeans_round(_ptr(lab), _ptr(labels), *shape, _ptr(centres),
+            check(lib.imgan_dcd_kmeans_round(_ptr(lab), _ptr(labels), *shape, cseed, _ptr(centres),
                                              _ptr(self.assign), _ptr(self.state),
                                              1 if (r == 0 and streaming_only) else 0,
                                              _ptr(self.active), _stream()))

@@ -11,7 +11,9 @@ Deviations of dominant colour from the reference, all stated in DESIGN.md:
   * the reference samples the initial centres with an unseeded random.sample (:79); here the
     sample comes from `random.Random(seed)` (seed=None keeps it non-deterministic) or from
     explicit `init` indices, so a run can be reproduced;
-  * an empty cluster keeps its centre instead of being re-sampled at random (:101);
+  * an empty cluster is re-seeded (:101) by a hash rule over the segment's pixels instead of an
+    unseeded random.sample (the rule: imgan.h at imgan_dcd_kmeans_round); its 32-bit seed is
+    drawn from the same `random.Random(seed)` and kept in `self.resample_seed`;
   * spatial coherence uses true 8-connected components; the reference clamps the
     neighbourhood at 255 (:52,:54), which is only correct for images up to 255 x 255.
 """
@@ -43,6 +45,7 @@ class MPEG7Descriptors(object):
         self.segments = set(clusters.flatten())
         self.segments.discard(-1)
         self._rng = random.Random(seed)
+        self.resample_seed = None
         self.dcd_rounds = {}
 
     # ------------------------------------------------------------------ helpers
@@ -79,21 +82,24 @@ class MPEG7Descriptors(object):
             out[j] = [mean, var, n / float(nseg_pixels), int(stats[j, 7]) / float(n)]
         return out
 
-    def _run_dcd(self, label_map, nseg, k, centres, streaming_only=False):
+    def _run_dcd(self, label_map, nseg, k, centres, streaming_only=False, resample_seed=None):
         H, W = label_map.shape
         plan = ops.DcdPlan(1, H, W, nseg, k)
         dev_labels = torch.from_numpy(np.ascontiguousarray(label_map)).cuda().unsqueeze(0)
         dev_centres = torch.from_numpy(np.ascontiguousarray(centres, dtype=np.float32)).cuda()
+        self.resample_seed = (self._rng.getrandbits(32) if resample_seed is None
+                              else int(resample_seed) & 0xffffffff)
         plan.kmeans(self._dev_lab, dev_labels, dev_centres.view(1, nseg, k, 3),
-                    streaming_only=streaming_only)
+                    streaming_only=streaming_only, resample_seed=self.resample_seed)
         stats = plan.statistics(self._dev_lab, dev_labels, streaming_only)[0].cpu().numpy()
         rounds, _ = plan.rounds()
         return stats, dev_centres.cpu().numpy().reshape(nseg, k, 3), rounds[0].cpu().numpy()
 
     # ------------------------------------------------------------------ dominant colour
-    def dominant_colour(self, num_dominant, segment, seg_idxs, init=None):
+    def dominant_colour(self, num_dominant, segment, seg_idxs, init=None, resample_seed=None):
         """mpeg7Descriptors.py:76-130 for one segment.
-        segment: N x 3 Lab points, seg_idxs: N x 2 (row, col); init: optional N-indices."""
+        segment: N x 3 Lab points, seg_idxs: N x 2 (row, col); init: optional N-indices;
+        resample_seed: optional seed of the draws that re-seed empty clusters (:101)."""
         segment = np.asarray(segment)
         seg_idxs = np.asarray(seg_idxs)
         if init is None:
@@ -101,12 +107,14 @@ class MPEG7Descriptors(object):
         label_map = np.full(self.clusters.shape, -1, dtype=np.int32)
         label_map[seg_idxs[:, 0], seg_idxs[:, 1]] = 0
         centres = segment[np.asarray(init)].astype(np.float32).reshape(1, num_dominant, 3)
-        stats, cen, rounds = self._run_dcd(label_map, 1, num_dominant, centres)
+        stats, cen, rounds = self._run_dcd(label_map, 1, num_dominant, centres,
+                                           resample_seed=resample_seed)
         return self._features(stats[0], cen[0], len(segment))
 
-    def mpeg7_dominant_colours(self, max_cols, init=None):
+    def mpeg7_dominant_colours(self, max_cols, init=None, resample_seed=None):
         """mpeg7Descriptors.py:132-141: {segment: {j: [mean, var, percentage, coherence]}}.
-        init: optional {segment: k point indices in raster order within the segment}."""
+        init: optional {segment: k point indices in raster order within the segment};
+        resample_seed: optional seed of the draws that re-seed empty clusters (:101)."""
         segs, label_map = self._segment_index_map()
         nseg = len(segs)
         order = np.argsort(label_map.ravel(), kind="stable")
@@ -123,7 +131,8 @@ class MPEG7Descriptors(object):
             if len(pick) != max_cols or (n and max(pick) >= n):
                 raise ValueError("Sample larger than population or is negative")
             centres[i] = lab_flat[order[starts[i] + np.asarray(pick)]]
-        stats, cen, rounds = self._run_dcd(label_map, nseg, max_cols, centres)
+        stats, cen, rounds = self._run_dcd(label_map, nseg, max_cols, centres,
+                                           resample_seed=resample_seed)
         dcd_per_seg = {}
         for i, seg in enumerate(segs):
             dcd_per_seg[int(seg)] = self._features(stats[i], cen[i], int(counts[i]))

@@ -211,11 +211,17 @@ int imgan_enforce_connectivity(const int32_t* labels, int32_t* out, int B, int H
  * before the first round.  One call = one Lloyd round (:86-107) for every
  * segment that has not met the stop rule yet; first_round != 0 also marks the
  * pixels outside every segment in `assign`.  active_out (device int32[1], may be
- * NULL) receives the number of segments still running.  k <= 16. */
+ * NULL) receives the number of segments still running.  k <= 16.
+ * A cluster that runs empty is re-seeded (:101).  The reference draws the pixel with an
+ * unseeded random.sample; here cluster j of a segment takes that segment's pixel p = y*W + x
+ * with the smallest (mix32((p * 0x9e3779b1 + seed) ^ ((j + 1) * 0x85ebca6b)), p), mix32 being
+ * the murmur3 finaliser: reproducible, independent of the round.  imgan_dcd_segments* follow
+ * the same rule with their `seed`. */
 size_t imgan_dcd_state_bytes(int B, int nseg, int k);
 int imgan_dcd_kmeans_round(const uint8_t* lab, const int32_t* labels, int B, int H, int W,
-                           int nseg, int k, float* centres, uint8_t* assign, void* state,
-                           int first_round, int32_t* active_out, imgan_stream_t stream);
+                           int nseg, int k, uint32_t seed, float* centres, uint8_t* assign,
+                           void* state, int first_round, int32_t* active_out,
+                           imgan_stream_t stream);
 /* Per-segment loop state: rounds_out / done_out int32 [B][nseg] (device). */
 int imgan_dcd_rounds(const void* state, int B, int nseg, int k, int32_t* rounds_out,
                      int32_t* done_out, imgan_stream_t stream);
@@ -234,7 +240,8 @@ int imgan_dcd_init_hash(const uint8_t* lab, const int32_t* labels, int B, int H,
  * reference's stop rule and writes centres, the per-pixel assignment, the per-segment round
  * count (state) and the integer statistics count / sums / sums of squares (stats slots 0-6).
  * use_hash_init != 0 samples the initial centres as imgan_dcd_init_hash does, otherwise
- * `centres` holds them on entry.  Segments too large for LDS are left untouched and counted in
+ * `centres` holds them on entry; `seed` also drives the re-seeding of empty clusters (see
+ * imgan_dcd_kmeans_round).  Segments too large for LDS are left untouched and counted in
  * n_big_out (device int32): the caller finishes them with imgan_dcd_init_hash /
  * imgan_dcd_kmeans_round, which skip the segments already done.  `state` needs no
  * initialisation; bbox_scratch: imgan_dcd_bbox_bytes() bytes. */

@@ -6,8 +6,8 @@
  *   oracle_slic_run     <- scripts/slic.py:35-127 (SLICSuperPixel.init_clusters / run), as restated
  *                          in oracle/slic_ref.py, literal float64 distance (slic.py:101-109)
  *   oracle_dcd_segment  <- scripts/mpeg7Descriptors.py:76-130 (dominant_colour), as restated in
- *                          oracle/dcd_ref.py (same stated deviations: injected initial points,
- *                          an empty cluster keeps its centre, true 8-connected coherence)
+ *                          oracle/dcd_ref.py (same stated deviations: injected initial points and
+ *                          re-sample points, true 8-connected coherence)
  *
  * Build: oracle/c/build.sh (gcc -O2 -fopenmp -ffp-contract=off: no fused multiply-adds, so the
  * float results are those of the numpy expressions evaluated operation by operation).
@@ -127,10 +127,11 @@ static int uf_find(int* par, int a) {
 }
 
 /* One segment.  pts: N x 3 u8 Lab; rc: N x 2 int32 (row, col) of the same pixels; init: k point
- * indices.  Out: assign int32[N], centres float[k*3], stats uint64[k*8] = {count, sum0, sum1,
+ * indices; resample: k point indices (the point cluster j takes whenever it is empty, :101) or
+ * NULL (it keeps its centre).  Out: assign int32[N], centres float[k*3], stats uint64[k*8] = {count, sum0, sum1,
  * sum2, sumsq0, sumsq1, sumsq2, largest 8-connected component}, rounds.  Returns 0, or < 0. */
-int oracle_dcd_segment(const uint8_t* pts, const int32_t* rc, int N, const int32_t* init, int k,
-                       int max_rounds, int32_t* assign, float* centres, uint64_t* stats,
+int oracle_dcd_segment(const uint8_t* pts, const int32_t* rc, int N, const int32_t* init,
+                       const int32_t* resample, int k, int max_rounds, int32_t* assign, float* centres, uint64_t* stats,
                        int32_t* rounds_out) {
     if (N < 1 || k < 1 || k > 64) return -1;
     float old[64][3];
@@ -171,6 +172,8 @@ int oracle_dcd_segment(const uint8_t* pts, const int32_t* rc, int N, const int32
         for (int j = 0; j < k; ++j)
             if (cnt[j])                                   /* float32 sums of small integers are exact */
                 for (int f = 0; f < 3; ++f) centres[j * 3 + f] = (float)sum[j][f] / (float)cnt[j];
+            else if (resample)                            /* :101, injected draw */
+                for (int f = 0; f < 3; ++f) centres[j * 3 + f] = (float)pts[(size_t)resample[j] * 3 + f];
         float sh[3] = {0.0f, 0.0f, 0.0f};
         for (int j = 0; j < k; ++j)
             for (int f = 0; f < 3; ++f) sh[f] = sh[f] + fabsf(centres[j * 3 + f] - old[j][f]);
@@ -277,7 +280,7 @@ int oracle_path_batch(const uint8_t* lab, int B, int H, int W, int K, double cw,
             uint8_t* pts = (uint8_t*)malloc((size_t)N * 3);
             int32_t* rc = (int32_t*)malloc((size_t)N * 2 * sizeof(int32_t));
             int32_t* as = (int32_t*)malloc((size_t)N * sizeof(int32_t));
-            int32_t init[64];
+            int32_t init[64], resample[64];
             float c[64 * 3];
             uint64_t st[64 * 8];
             int32_t rounds = 0;
@@ -287,8 +290,11 @@ int oracle_path_batch(const uint8_t* lab, int B, int H, int W, int K, double cw,
                 rc[2 * i] = p / W;
                 rc[2 * i + 1] = p % W;
             }
-            for (int j = 0; j < k; ++j) init[j] = (int)(((int64_t)j * N) / k);
-            if (oracle_dcd_segment(pts, rc, N, init, k, 1000, as, c, st, &rounds)) fail |= 1;
+            for (int j = 0; j < k; ++j) {
+                init[j] = (int)(((int64_t)j * N) / k);
+                resample[j] = (int)(((int64_t)(2 * j + 1) * N) / (2 * k));
+            }
+            if (oracle_dcd_segment(pts, rc, N, init, resample, k, 1000, as, c, st, &rounds)) fail |= 1;
             rt += (int64_t)rounds * N;
             free(pts);
             free(rc);

@@ -29,8 +29,8 @@ def lib():
         _lib.oracle_slic_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _lib.oracle_dcd_segment.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + \
-            [ctypes.c_void_p] * 4
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                            ctypes.c_int] + [ctypes.c_void_p] * 4
     return _lib
 
 
@@ -56,8 +56,9 @@ def slic_run(lab_u8, K, colour_weight, num_iter):
     return labels, centres[:n]
 
 
-def dcd_segment(points_u8, seg_idxs, init_idx, max_rounds=1000):
-    """-> (assign int32 [N], centres float32 [k, 3], stats uint64 [k, 8], rounds)."""
+def dcd_segment(points_u8, seg_idxs, init_idx, max_rounds=1000, resample_idx=None):
+    """-> (assign int32 [N], centres float32 [k, 3], stats uint64 [k, 8], rounds).
+    resample_idx: the point each cluster takes when it is empty (None: it keeps its centre)."""
     L = lib()
     pts = np.ascontiguousarray(points_u8, dtype=np.uint8)
     rcs = np.ascontiguousarray(seg_idxs, dtype=np.int32)
@@ -67,7 +68,9 @@ def dcd_segment(points_u8, seg_idxs, init_idx, max_rounds=1000):
     centres = np.empty((k, 3), np.float32)
     stats = np.empty((k, 8), np.uint64)
     rounds = ctypes.c_int32()
-    rc = L.oracle_dcd_segment(_p(pts), _p(rcs), N, _p(init), k, int(max_rounds), _p(assign),
+    res = None if resample_idx is None else np.ascontiguousarray(resample_idx, dtype=np.int32)
+    rc = L.oracle_dcd_segment(_p(pts), _p(rcs), N, _p(init), None if res is None else _p(res), k,
+                              int(max_rounds), _p(assign),
                               _p(centres), _p(stats), ctypes.byref(rounds))
     if rc:
         raise RuntimeError("oracle_dcd_segment failed (%d)" % rc)

@@ -7,8 +7,10 @@ Follows /root/reference/scripts/mpeg7Descriptors.py:20-26 (constructor),
 Stated deviations:
   * the reference draws the initial centres with an unseeded random.sample
     (:79); here the caller injects the initial point indices.
-  * an empty cluster is re-sampled at random in the reference (:101); here it
-    keeps its centre (deterministic).  A cluster that is empty at the end
+  * an empty cluster is re-sampled with an unseeded random.sample in the
+    reference (:101); here the caller injects, per cluster, the index of the
+    point that cluster takes whenever it is empty (resample_idx; without it
+    the cluster keeps its centre).  A cluster that is empty at the end
     reports var = NaN, percentage 0, coherence 0 (the reference would raise
     at :128 on max([])).
   * spatial coherence is the true 8-connected component size; the reference's
@@ -24,8 +26,38 @@ from .color import bgr2lab_u8, bgr2gray_u8
 _EIGHT = np.ones((3, 3), dtype=bool)
 
 
-def lloyd(points_u8, init_idx, max_rounds=1000):
-    """mpeg7Descriptors.py:78-107.  points_u8: N x 3 uint8 Lab, init_idx: k indices.
+def mix32(h):
+    """murmur3 finaliser on uint32 values held in uint64 arrays."""
+    h = np.asarray(h).astype(np.uint64)
+    m = np.uint64(0xffffffff)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85ebca6b)) & m
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xc2b2ae35)) & m
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def hash_resample_idx(flat_idx, seed, k):
+    """The draws this repository puts in the place of random.sample(segment, 1) at :101 (the
+    reference's are unseeded, so any draw is a run the reference could have made): cluster j of a
+    segment takes the pixel p = y*W + x with the smallest
+        (mix32((p * 0x9e3779b1 + seed) ^ ((j + 1) * 0x85ebca6b)), p)      (uint32 arithmetic).
+    flat_idx: the segment's pixels as flat indices in raster order.  Returns, per cluster, the
+    index into that list (the resample_idx of lloyd / dominant_colour)."""
+    m = np.uint64(0xffffffff)
+    p = np.asarray(flat_idx).astype(np.uint64)
+    out = []
+    for j in range(k):
+        salt = np.uint64(((j + 1) * 0x85ebca6b) & 0xffffffff)
+        h = mix32(((p * np.uint64(0x9e3779b1) + np.uint64(int(seed) & 0xffffffff)) & m) ^ salt)
+        out.append(int(np.lexsort((p, h))[0]))
+    return out
+
+
+def lloyd(points_u8, init_idx, max_rounds=1000, resample_idx=None):
+    """mpeg7Descriptors.py:78-107.  points_u8: N x 3 uint8 Lab, init_idx: k indices,
+    resample_idx: k indices (the point cluster j takes when it is empty, :101) or None.
     Returns (assignment int32[N], centres float32[k,3], rounds)."""
     segment = np.asarray(points_u8, dtype=np.float32)
     k = len(init_idx)
@@ -49,7 +81,9 @@ def lloyd(points_u8, init_idx, max_rounds=1000):
             if n:
                 s = np.sum(segment[cl_idx], axis=0, dtype=np.float32)
                 centers[c] = (s / np.float32(n)).astype(np.float32)
-            # else: keeps its centre (deviation, see header)
+            elif resample_idx is not None:
+                centers[c] = segment[resample_idx[c]].copy()         # :101, injected draw
+            # else: keeps its centre
         shift = np.zeros(3, dtype=np.float32)
         for cnt, old in zip(centers, old_cen):
             shift = shift + np.abs(cnt - old)                         # float32 adds, cluster order
@@ -61,10 +95,10 @@ def lloyd(points_u8, init_idx, max_rounds=1000):
     return clusters.astype(np.int32), np.stack(centers).astype(np.float32), rounds
 
 
-def dominant_colour(points_u8, seg_idxs, init_idx, shape):
+def dominant_colour(points_u8, seg_idxs, init_idx, shape, resample_idx=None):
     """mpeg7Descriptors.py:76-130 for one segment.
     seg_idxs: N x 2 (row, col) of the segment's pixels; shape: (H, W)."""
-    assign, centers, rounds = lloyd(points_u8, init_idx)
+    assign, centers, rounds = lloyd(points_u8, init_idx, resample_idx=resample_idx)
     pts = np.asarray(points_u8, dtype=np.float64)
     N = pts.shape[0]
     feats = {}
@@ -94,8 +128,9 @@ class DCDOracle(object):
         self.clusters = clusters
         self.segments = sorted(set(np.unique(clusters).tolist()) - {-1.0})
 
-    def mpeg7_dominant_colours(self, max_cols, init_fn):
-        """init_fn(segment_id, N, k) -> k point indices (raster order within the segment)."""
+    def mpeg7_dominant_colours(self, max_cols, init_fn, resample_fn=None):
+        """init_fn(segment_id, N, k) -> k point indices (raster order within the segment);
+        resample_fn likewise: the point each cluster takes when it is empty (:101)."""
         out = {}
         self.rounds = {}
         for seg in self.segments:
@@ -103,6 +138,7 @@ class DCDOracle(object):
             seg_idxs = np.transpose(np.nonzero(idx))
             pts = self.image_lab[idx]
             init = init_fn(int(seg), pts.shape[0], max_cols)
+            res = resample_fn(int(seg), pts.shape[0], max_cols) if resample_fn else None
             out[int(seg)], self.rounds[int(seg)] = dominant_colour(pts, seg_idxs, init,
-                                                                   self.clusters.shape)
+                                                                   self.clusters.shape, res)
         return out

@@ -23,3 +23,7 @@ from oracle.synth import voronoi_image  # noqa: E402,F401
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# the product's stand-in for the re-sample draw of mpeg7Descriptors.py:101, restated beside the oracle
+from oracle.dcd_ref import mix32, hash_resample_idx as resample_rule      # noqa: E402,F401

@@ -6,7 +6,7 @@ test_gpu_descriptors.py / test_gpu_fullsize_oracle.py."""
 import numpy as np
 import pytest
 
-from conftest import voronoi_image
+from conftest import voronoi_image, resample_rule
 
 pytestmark = pytest.mark.gpu
 
@@ -167,3 +167,50 @@ def test_listed_with_wrong_counts_stays_in_bounds():
     for s in (0, 1, 2):
         assert np.array_equal(stats[s], good[2][0, s])
     assert stats[:, :, 0].sum() <= H * W
+
+
+@pytest.mark.parametrize("levels", [32, 64, 128])
+def test_empty_clusters_are_reseeded_the_same_way_everywhere(levels):
+    """Quantised colours: sampled centres coincide, clusters run empty and are re-seeded
+    (mpeg7Descriptors.py:101, hash rule in place of random.sample).  The pixel lists, the box
+    gather and the streaming rounds must agree bit for bit, and with the oracle given the same
+    draws."""
+    torch = _torch()
+    from imgan import ops
+    from oracle.color import bgr2lab_u8
+    from oracle import c_oracle
+    H, W, k, seed = 120, 200, 6, 4242 + levels
+    img = (voronoi_image(H, W, 60, seed=levels, noise=3.0) // levels * levels).astype(np.uint8)
+    labf = bgr2lab_u8(img)
+    lab = torch.from_numpy(labf).cuda().unsqueeze(0)
+    labels = (np.arange(H)[:, None] // 40 * 5 + np.arange(W)[None, :] // 40).astype(np.int32)
+    nseg = 15
+    dl = torch.from_numpy(labels).cuda().unsqueeze(0)
+    rng = np.random.RandomState(levels)
+    flat = labels.ravel()
+    cen0 = np.zeros((1, nseg, k, 3), dtype=np.float32)
+    inits = {}
+    for s in range(nseg):
+        idx = np.nonzero(flat == s)[0]
+        inits[s] = np.sort(rng.choice(len(idx), k, replace=False)).astype(np.int32)
+        cen0[0, s] = labf.reshape(-1, 3)[idx[inits[s]]]
+    a = _run(ops, torch, lab, dl, nseg, k, False, cen0=cen0, resample_seed=seed)
+    b = _run(ops, torch, lab, dl, nseg, k, True, cen0=cen0, resample_seed=seed)
+    c = _run(ops, torch, lab, dl, nseg, k, True, cen0=cen0, resample_seed=seed, streaming_only=True)
+    _same(a, b)
+    for i in range(5):
+        assert np.array_equal(a[i], c[i]), i
+    reseeded = 0
+    for s in range(nseg):
+        idx = np.nonzero(flat == s)[0]
+        rc = np.stack(np.divmod(idx, W), axis=1).astype(np.int32)
+        res = resample_rule(idx, seed, k)
+        w_assign, w_cen, w_stats, w_rounds = c_oracle.dcd_segment(labf.reshape(-1, 3)[idx], rc,
+                                                                  inits[s], resample_idx=res)
+        k_assign, _, _, k_rounds = c_oracle.dcd_segment(labf.reshape(-1, 3)[idx], rc, inits[s])
+        reseeded += int(k_rounds != w_rounds or not np.array_equal(k_assign, w_assign))
+        assert b[3][0, s] == w_rounds, s
+        assert np.array_equal(b[1][0].ravel()[idx], w_assign.astype(np.uint8)), s
+        assert np.array_equal(b[0][0, s].view(np.uint32), w_cen.view(np.uint32)), s
+        assert np.array_equal(b[2][0, s].astype(np.uint64), w_stats), s
+    assert reseeded > 0                    # the draws did change the outcome of some segment

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import voronoi_image
+from conftest import voronoi_image, resample_rule, mix32 as _mix32
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +55,12 @@ def _merged_clusters(img, K):
     return rag.concat_similar_regs(rag.find_edges(ng, col), cl, c_factor=0.65)[0]
 
 
+def _resample_fn(clusters, mp):
+    """resample_fn for DCDOracle: the hash rule of the product with the seed the class drew."""
+    flat = np.asarray(clusters).ravel()
+    return lambda seg, n, kk: resample_rule(np.nonzero(flat == seg)[0], mp.resample_seed, kk)
+
+
 @pytest.mark.parametrize("H,W,K,k", [(120, 160, 60, 8), (213, 320, 200, 8), (90, 110, 30, 3)])
 def test_dominant_colour_matches_oracle(H, W, K, k):
     torch = _torch()
@@ -72,7 +78,7 @@ def test_dominant_colour_matches_oracle(H, W, K, k):
     mp = MPEG7Descriptors(clusters, img)
     got = mp.mpeg7_dominant_colours(k, init=init)
     ora = DCDOracle(clusters, img)
-    want = ora.mpeg7_dominant_colours(k, lambda seg, n, kk: init[seg])
+    want = ora.mpeg7_dominant_colours(k, lambda seg, n, kk: init[seg], _resample_fn(clusters, mp))
     assert got.keys() == want.keys()
     for seg in want:
         assert mp.dcd_rounds[seg] == ora.rounds[seg], seg            # same stop round
@@ -101,10 +107,10 @@ def test_dominant_colour_exact_ties(levels):
     clusters = (np.arange(W)[None, :] // 40 + 0 * np.arange(H)[:, None]).astype(np.float64)
     rng = np.random.RandomState(levels)
     init = {seg: sorted(rng.choice(H * 40, k, replace=False).tolist()) for seg in range(4)}
-    mp = MPEG7Descriptors(clusters, img)
+    mp = MPEG7Descriptors(clusters, img, seed=levels)
     got = mp.mpeg7_dominant_colours(k, init=init)
     ora = DCDOracle(clusters, img)
-    want = ora.mpeg7_dominant_colours(k, lambda seg, n, kk: init[seg])
+    want = ora.mpeg7_dominant_colours(k, lambda seg, n, kk: init[seg], _resample_fn(clusters, mp))
     empties = 0
     for seg in want:
         assert mp.dcd_rounds[seg] == ora.rounds[seg], seg
@@ -135,7 +141,8 @@ def test_dominant_colour_single_segment_api():
     pts = bgr2lab_u8(img)[idx]
     init = [5, 100, 700, 1500]
     got = mp.dominant_colour(4, pts, seg_idxs, init=init)
-    want, _ = dominant_colour(pts, seg_idxs, init, clusters.shape)
+    res = resample_rule(np.nonzero(idx.ravel())[0], mp.resample_seed, 4)
+    want, _ = dominant_colour(pts, seg_idxs, init, clusters.shape, res)
     for j in range(4):
         assert np.allclose(got[j][0], want[j][0], rtol=1e-4)
         assert got[j][2] == want[j][2] and got[j][3] == want[j][3]
@@ -199,17 +206,6 @@ def test_descriptor_methods_on_class():
     assert list(shape) == [0] and np.array(shape[0]).shape == (3, 12)
 
 
-def _mix32(h):
-    h = h.astype(np.uint64)
-    m = np.uint64(0xffffffff)
-    h ^= h >> np.uint64(16)
-    h = (h * np.uint64(0x85ebca6b)) & m
-    h ^= h >> np.uint64(13)
-    h = (h * np.uint64(0xc2b2ae35)) & m
-    h ^= h >> np.uint64(16)
-    return h
-
-
 def test_full_pipeline_batch_matches_oracle():
     """configs[1] in miniature: Lab -> SLIC -> per-superpixel dominant colours (device-side
     hash init) + CLD/EHD/CSD for a batch of 2, each stage against the oracle."""
@@ -253,7 +249,7 @@ def test_full_pipeline_batch_matches_oracle():
                 init.append(int(best))
             pts = lab.reshape(-1, 3)[idx]
             seg_idxs = np.stack(np.divmod(idx, W), axis=1)
-            want_f, _ = dominant_colour(pts, seg_idxs, init, (H, W))
+            want_f, _ = dominant_colour(pts, seg_idxs, init, (H, W), resample_rule(idx, seed, k))
             for j in range(k):
                 wm, wv, wp, wc = want_f[j]
                 g = feats[b, s, j]

@@ -11,7 +11,7 @@ SLIC and Lloyd loops affordable at these sizes; the rest is the numpy oracle its
 import numpy as np
 import pytest
 
-from conftest import voronoi_image
+from conftest import voronoi_image, resample_rule
 
 pytestmark = pytest.mark.gpu
 
@@ -86,10 +86,11 @@ def test_1080p_k400_whole_path_against_oracles():
         init = np.sort(rng.choice(len(idx), k, replace=False)).astype(np.int32)
         cen0[0, s] = labf[idx[init]]
         rc = np.stack(np.divmod(idx, W), axis=1).astype(np.int32)
-        want[s] = (idx,) + c_oracle.dcd_segment(labf[idx], rc, init)
+        want[s] = (idx,) + c_oracle.dcd_segment(labf[idx], rc, init,
+                                                resample_idx=resample_rule(idx, 2468, k))
     dcd = ops.DcdPlan(1, H, W, n, k)
     cen = torch.from_numpy(cen0).cuda()
-    dcd.kmeans(lab, labels, cen, max_rounds=1000)
+    dcd.kmeans(lab, labels, cen, max_rounds=1000, resample_seed=2468)
     stats = dcd.statistics(lab, labels).cpu().numpy()[0]
     rounds = dcd.rounds()[0].cpu().numpy()[0]
     assign = dcd.assign[0].cpu().numpy().ravel()

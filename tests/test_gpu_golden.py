@@ -53,7 +53,7 @@ def test_pipeline_reproduces_golden(name, k):
 
     mp = MPEG7Descriptors(new, img)
     init = {int(s): f["dcd_init"][i].tolist() for i, s in enumerate(f["dcd_segments"])}
-    dcd = mp.mpeg7_dominant_colours(k, init=init)
+    dcd = mp.mpeg7_dominant_colours(k, init=init, resample_seed=int(f["dcd_resample_seed"]))
     for i, s in enumerate(f["dcd_segments"]):
         s = int(s)
         assert mp.dcd_rounds[s] == f["dcd_rounds"][i]

@@ -81,6 +81,11 @@ def test_dcd_stop_rule_and_ties():
     assign, cen, rounds = lloyd(pts, [0, 1], max_rounds=1)
     assert set(assign.tolist()) == {0}
     assert cen[1].tolist() == [10.0, 10.0, 10.0]      # empty cluster keeps its centre
+    # with an injected re-sample draw (:101) the empty cluster moves to that point, takes its
+    # five pixels in the next round and the loop ends on the two colours
+    assign, cen, rounds = lloyd(pts, [0, 1], resample_idx=[3, 7])
+    assert assign.tolist() == [0] * 5 + [1] * 5
+    assert cen[0].tolist() == [10.0, 10.0, 10.0] and cen[1].tolist() == [200.0, 50.0, 50.0]
 
 
 @pytest.mark.parametrize("name", ["road_320", "bear_320", "synth_96x64"])
@@ -98,6 +103,20 @@ def test_oracle_reproduces_golden(name):
     assert np.array_equal(np.concatenate(M.edge_histogram_counts(img)), f["ehd"])
     h, n = M.colour_structure_counts(img)
     assert np.array_equal(h, f["csd"][:-1]) and n == f["csd"][-1]
+    # dominant colours of the merged regions: injected initial points and re-sample draws
+    from oracle.dcd_ref import DCDOracle, hash_resample_idx
+    init = {int(s): f["dcd_init"][i].tolist() for i, s in enumerate(f["dcd_segments"])}
+    flat = f["merged"].ravel()
+    d = DCDOracle(f["merged"].astype(np.float64), img)
+    k = f["dcd_init"].shape[1]
+    feats = d.mpeg7_dominant_colours(
+        k, lambda seg, n_, kk: init[seg],
+        lambda seg, n_, kk: hash_resample_idx(np.nonzero(flat == seg)[0], int(f["dcd_resample_seed"]), kk))
+    for i, s in enumerate(f["dcd_segments"]):
+        assert d.rounds[int(s)] == f["dcd_rounds"][i]
+        for j in range(k):
+            assert np.array_equal(feats[int(s)][j][0], f["dcd_mean"][i, j])
+            assert feats[int(s)][j][2] == f["dcd_pct"][i, j] and feats[int(s)][j][3] == f["dcd_coh"][i, j]
 
 
 def test_mpeg7_std_sanity():

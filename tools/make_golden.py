@@ -18,11 +18,12 @@ sys.path.insert(0, ROOT)
 from oracle.color import bgr2lab_u8, bgr2gray_u8, median_blur     # noqa: E402
 from oracle.slic_ref import SLICOracle                            # noqa: E402
 from oracle.rag_ref import RAGOracle                              # noqa: E402
-from oracle.dcd_ref import DCDOracle                              # noqa: E402
+from oracle.dcd_ref import DCDOracle, hash_resample_idx          # noqa: E402
 from oracle import mpeg7_std as M                                 # noqa: E402
 from oracle.synth import voronoi_image                            # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
+RESAMPLE_SEED = 20261111          # seed of the re-sample draws (mpeg7Descriptors.py:101) in the fixtures
 REF_DATA = "/root/reference/data"
 
 
@@ -67,7 +68,11 @@ def make(name, img, K=200, k=8):
     )
     if ok:
         d = DCDOracle(merged, img)
-        feats = d.mpeg7_dominant_colours(k, lambda seg, n, kk: init[seg])
+        flat = merged.ravel()
+        feats = d.mpeg7_dominant_colours(
+            k, lambda seg, n, kk: init[seg],
+            lambda seg, n, kk: hash_resample_idx(np.nonzero(flat == seg)[0], RESAMPLE_SEED, kk))
+        out["dcd_resample_seed"] = np.int64(RESAMPLE_SEED)
         segs = sorted(feats.keys())
         out["dcd_segments"] = np.array(segs, dtype=np.int32)
         out["dcd_init"] = np.array([init[s] for s in segs], dtype=np.int32)

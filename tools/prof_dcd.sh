@@ -1,6 +1,9 @@
-# kernel tables of the dominant-colour stage, pixel lists against the box gather (run on the GPU box)
+# kernel table of the dominant-colour stage for the product library and experiment builds (GPU box)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-K=${1:-400}
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_lists -o l -- python3 tools/time_dcd.py 64 lists $K > gpurun_out/kt_lists.log 2>&1 || exit 1
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_gather -o g -- python3 tools/time_dcd.py 64 gather $K nolists > gpurun_out/kt_gather.log 2>&1 || exit 1
-python3 tools/kstats.py gpurun_out/kt_lists 6 && python3 tools/kstats.py gpurun_out/kt_gather 6
+K=${K:-400}
+for v in product $VARIANTS; do
+  if [ $v = product ]; then unset IMGAN_LIB; else export IMGAN_LIB=$PWD/image-analysis_amd/imgan/exp/$v.so; fi
+  rm -rf gpurun_out/kt_$v
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt_$v -o k -- python3 tools/time_dcd.py 64 $v $K > gpurun_out/kt_$v.log 2>&1 || exit 1
+  echo "== $v"; python3 tools/kstats.py gpurun_out/kt_$v 6 | grep "seg_\|dcd_segment"
+done
