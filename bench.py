@@ -297,10 +297,11 @@ def run_config_mosaic(steps, warmup):
            "value": round(npix * steps / dt / 1e6, 2), "unit": "megapixels/sec",
            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "dcd_segments_at_round_cap": pipe.segments_at_round_cap(),
-           "roofline": roofline_line("dcd_segment_kernel", ms["dcd_segments"], dcd_bytes, npix, profile=prof,
-                                     bound="valu/lds",
-                                     note="SURVEY 8d figure 8*T+13*P; the Lloyd rounds run in LDS, "
-                                          "compulsory HBM traffic is 8 B/px"),
+           "roofline": roofline_line("dcd_segment_kernel x3 tiers (+seg_scatter_kernel, seg_plan_kernel)",
+                                     ms["dcd_segments"], dcd_bytes, npix, profile=prof, bound="valu/lds",
+                                     note="timed around the C call (imgan_dcd_segments_listed); SURVEY 8d "
+                                          "figure 8*T+13*P; the Lloyd rounds run in LDS, compulsory HBM "
+                                          "traffic is 24 B/px (sort pass in and out, lists in, assignment out)"),
            "roofline_kernels": [roofline_line("slic_assign_kernel", ms["slic_assign"], 7, npix, profile=prof,
                                               launches=9),
                                 roofline_line("region_desc_kernel (+cld_finalise)", ms["region_desc"], 21, npix,

@@ -162,33 +162,45 @@ __global__ void slic_prepare_kernel(const uint8_t* __restrict__ lab,
     for (int k = 0; k < NFIELD; ++k) s[k] = 0ull;
 }
 
-// one workgroup per image: exclusive scan of the cell counts
+// one workgroup per image: exclusive scan of the cell counts.  Four cells per thread, the running
+// sum inside a wave by lane shuffles, across the waves through 16 words of LDS: two barriers per
+// 4096 cells (a Hillis-Steele scan over LDS took twenty per 1024: 89 us per round on the 50,000
+// cells of the 16384^2 mosaic).
 __global__ __launch_bounds__(1024) void slic_scan_kernel(Ws w) {
-    __shared__ int part[1024];
+    __shared__ int wave_sum[16];
     __shared__ int carry;
-    int b = blockIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int* cnt = w.count + (size_t)b * w.ncell;
     int* start = w.start + (size_t)b * (w.ncell + 1);
-    if (threadIdx.x == 0) carry = 0;
+    if (tid == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < w.ncell; base += 1024) {
-        int i = base + threadIdx.x;
-        int v = (i < w.ncell) ? cnt[i] : 0;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int add = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
-            __syncthreads();
-            part[threadIdx.x] += add;
-            __syncthreads();
+    for (int base = 0; base < w.ncell; base += 4096) {
+        const int i0 = base + tid * 4;
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i0 + u < w.ncell) ? cnt[i0 + u] : 0;
+        const int mine = (v[0] + v[1]) + (v[2] + v[3]);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
         }
-        int incl = part[threadIdx.x];
-        if (i < w.ncell) start[i] = carry + incl - v;
+        if (lane == 63) wave_sum[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 1023) carry += incl;
+        int before = carry;
+        for (int q = 0; q < wave; ++q) before += wave_sum[q];
+        int run = before + incl - mine;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u < w.ncell) start[i0 + u] = run;
+            run += v[u];
+        }
+        __syncthreads();
+        if (tid == 1023) carry = run;
         __syncthreads();
     }
-    if (threadIdx.x == 0) start[w.ncell] = carry;
+    if (tid == 0) start[w.ncell] = carry;
 }
 
 __global__ void slic_fill_kernel(Ws w, int B, int n) {

@@ -20,5 +20,5 @@ r = d["roofline"]
 print(d["value"], d["ms_per_step"], r["launch_ms"], r["frac"], r["traffic"] and r["traffic"] / r["algorithmic_bytes_per_launch"])
 for k in d["roofline_kernels"]: print(k["kernel"], k["launch_ms"], k["achieved"], k["frac"])
 print(d["path"]); print(d["cpu_baseline"])
-for c in d["configs"]: print(c["config"]["workload"][:60], c["ms_per_step"], c["value"], c["roofline"]["frac"], c["path"]["frac"])
+for c in d["configs"]: print(str(c.get("config"))[:70], c.get("ms_per_step"), c.get("value"))
 PY
