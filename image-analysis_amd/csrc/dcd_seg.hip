@@ -644,8 +644,10 @@ __device__ __forceinline__ bool segment_body(
             s_done = 0;                                 // DEDUP: raised when the colour table is full
         }
         if (tid < KM) slots[tid] = ~0ull;
-        if (DEDUP)
+        if (DEDUP) {
             for (int i = tid; i < TU; i += THREADS) pix[i] = NO_COLOUR;
+            for (int i = tid; i < TU / 2; i += THREADS) reinterpret_cast<uint32_t*>(ucnt)[i] = 0u;
+        }
         __syncthreads();
         const int nrun = (int)min(run_n, (uint32_t)CAP);
         const bool kpow2 = (k & (k - 1)) == 0;
@@ -676,6 +678,8 @@ __device__ __forceinline__ bool segment_body(
                     }
                     if (probe == DEDUP_PROBES) s_done = 1;
                     idx[i] = (uint16_t)slot;
+                    // two 16-bit counts per word; no carry: a count is at most n < 65536
+                    atomicAdd(reinterpret_cast<uint32_t*>(ucnt) + (slot >> 1), 1u << ((slot & 1u) * 16u));
                 } else {
                     pix[i] = v[u] & 0xffffffu;
                     pos[i] = (uint16_t)(__mul24(y - ymin, bw) + (x - xmin));
@@ -695,19 +699,21 @@ __device__ __forceinline__ bool segment_body(
         big = false;
         if (DEDUP) {
             if (s_done) return false;                   // too many colours: the caller runs the plain body
-            // ---- close the table up.  Every thread takes TC consecutive slots into registers and
-            // counts the occupied ones; a running sum over the block gives every colour its dense
-            // index, left in the count array for the moment (slot -> index); the pixels swap their
-            // slot for the index, the colours move to their dense places, the counts are tallied.
+            // ---- close the table up.  Every thread takes TC consecutive slots (colour and count)
+            // into registers; a running sum of the occupied ones over the block gives every colour
+            // its dense index, left in its slot for the moment; the pixels swap their slot for the
+            // index; the colours and counts move to their dense places.
             constexpr int TC = (TU + THREADS - 1) / THREADS;
-            uint32_t held[TC];
-            int mine = 0;
+            uint32_t held[TC], occupied = 0;
+            uint16_t held_n[TC];
 #pragma unroll
             for (int j = 0; j < TC; ++j) {
-                const int slot = tid * TC + j;
-                held[j] = slot < TU ? pix[slot] : NO_COLOUR;
-                mine += held[j] != NO_COLOUR;
+                const int slot = min(tid * TC + j, TU - 1);
+                held[j] = pix[slot];
+                held_n[j] = ucnt[slot];
+                if (tid * TC + j < TU && held[j] != NO_COLOUR) occupied |= 1u << j;
             }
+            const int mine = __popc(occupied);
             int incl = mine;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -726,26 +732,22 @@ __device__ __forceinline__ bool segment_body(
             {
                 int id = first;
 #pragma unroll
-                for (int j = 0; j < TC; ++j) {
-                    const int slot = tid * TC + j;
-                    if (slot < TU && held[j] != NO_COLOUR) ucnt[slot] = (uint16_t)id++;
-                }
+                for (int j = 0; j < TC; ++j)
+                    if ((occupied >> j) & 1u) pix[tid * TC + j] = (uint32_t)id++;
             }
             if (tid == 0) s_unique = total;
-            __syncthreads();                            // every slot is in a register, every index known
-            for (int i = tid; i < nrun; i += THREADS) idx[i] = ucnt[idx[i]];
+            __syncthreads();                            // every slot holds its index now
+            for (int i = tid; i < nrun; i += THREADS) idx[i] = (uint16_t)pix[idx[i]];
+            __syncthreads();
             {
                 int id = first;
 #pragma unroll
                 for (int j = 0; j < TC; ++j)
-                    if (held[j] != NO_COLOUR) pix[id++] = held[j];
-            }
-            __syncthreads();
-            for (int i = tid; i < (total + 1) / 2; i += THREADS) reinterpret_cast<uint32_t*>(ucnt)[i] = 0u;
-            __syncthreads();
-            for (int i = tid; i < nrun; i += THREADS) {
-                const uint32_t id = idx[i];             // two 16-bit counts per word; no carry: <= n < 65536
-                atomicAdd(reinterpret_cast<uint32_t*>(ucnt) + (id >> 1), 1u << ((id & 1u) * 16u));
+                    if ((occupied >> j) & 1u) {
+                        pix[id] = held[j];
+                        ucnt[id] = held_n[j];
+                        ++id;
+                    }
             }
             __syncthreads();
         }
@@ -1600,7 +1602,7 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
             T))                                                                                       \
         return rc;
     if (k <= 8 && dedup) {
-        TIER(8, CAP_LARGE, THREADS_LARGE, MODE_LISTED, 1, 2)
+        TIER(8, CAP_LARGE, THREADS_LARGE, MODE_DEDUP, 1, 2)
         TIER(8, CAP_SMALL_D, THREADS_SMALL, MODE_DEDUP, 2, 1)
         TIER(8, CAP_TINY_D, THREADS_TINY, MODE_DEDUP, 3, 0)
     } else if (k <= 8) {
