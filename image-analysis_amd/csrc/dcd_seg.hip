@@ -63,6 +63,9 @@ constexpr int CAP_SMALL = 12288, THREADS_SMALL = 768;       // 6 B of LDS per pi
 // smaller tiers sized so that the 32-bit accumulators of the dedup kernels fit beside the pixels
 constexpr int CAP_TINY_D = 7168, THREADS_TINY = 512;       // 512 x 14
 constexpr int CAP_SMALL_D = 11520;                         // 768 x 15
+// (A fourth tier below these, 5,376 px / 384 threads = four workgroups per CU, was measured: 4.46
+// against 4.16 ms at K = 400 and 5.6 against 4.9 at K = 800 -- six waves do not spread over four
+// SIMDs, the same finding as for 640 and 896 threads.)
 constexpr int CAP_SMALL_K16 = 10752;   // 9 .. 16 colours: twice the accumulators, still two workgroups per CU
 constexpr int CAP_LARGE = 22528, THREADS_LARGE = 1024;     // >= 4 S^2 of the 1080p / K=400 grid
 // The small tier packs {count, sum0} and {sum1, sum2} into 16-bit halves of two words per
