@@ -72,15 +72,15 @@ def test_slic_label_counts_are_the_counts_of_the_label_map():
 
 @pytest.mark.parametrize("k", [3, 8, 12])
 def test_listed_equals_gather_on_superpixels(k):
-    """SLIC superpixels of two images (all three tiers for k <= 8: small, medium and a few large
-    segments), hash-sampled initial centres."""
+    """SLIC superpixels of two images (all three tiers for k <= 8 -- 7,168 / 11,520 / 22,528 px, in
+    dedup mode -- and the two plain tiers for k = 12), hash-sampled initial centres."""
     torch = _torch()
     from imgan import ops
     from oracle.color import bgr2lab_u8
     H, W = 360, 500
     imgs = np.stack([voronoi_image(H, W, 50, seed=7 + i, noise=14.0) for i in range(2)])
     lab = torch.from_numpy(np.stack([bgr2lab_u8(im) for im in imgs])).cuda()
-    # 30 clusters -> S = 77, superpixels of ~9000 px: the tiers 7680 / 12288 / 22528 all get some
+    # 30 clusters -> S = 77, superpixels of ~9000 px: every tier gets some
     slic = ops.SlicPlan(2, H, W, 30)
     slic.run(lab, 20.0, 4)
     dl = slic.labels
@@ -89,7 +89,7 @@ def test_listed_equals_gather_on_superpixels(k):
     _same(a, b)
     first = dl[0].cpu().numpy().ravel()
     sizes = np.bincount(first[first >= 0])
-    assert (sizes <= 7680).any() and ((sizes > 7680) & (sizes <= 22528)).any(), sizes
+    assert (sizes <= 7168).any() and ((sizes > 11520) & (sizes <= 22528)).any(), sizes
 
 
 def test_listed_equals_gather_edge_cases():
@@ -214,3 +214,29 @@ def test_empty_clusters_are_reseeded_the_same_way_everywhere(levels):
         assert np.array_equal(b[0][0, s].view(np.uint32), w_cen.view(np.uint32)), s
         assert np.array_equal(b[2][0, s].astype(np.uint64), w_stats), s
     assert reseeded > 0                    # the draws did change the outcome of some segment
+
+
+def test_dedup_table_overflow_falls_back_to_the_plain_body():
+    """Uniform colour noise: nearly every pixel of a segment has a colour of its own, the colour
+    table of the dedup tiers overflows and the workgroup runs the plain body on the segment; flat
+    colours beside it: a handful of table entries.  Both must equal the box gather bit for bit."""
+    torch = _torch()
+    from imgan import ops
+    rng = np.random.RandomState(11)
+    H, W, k = 240, 400, 8
+    labf = rng.randint(0, 256, size=(H, W, 3)).astype(np.uint8)        # taken as Lab directly
+    labf[:, 300:] = (labf[:, 300:] // 128) * 128                       # 8 colours on the right
+    lab = torch.from_numpy(labf).cuda().unsqueeze(0)
+    labels = np.full((H, W), -1, dtype=np.int32)
+    labels[0:70, 0:100] = 0            # 7,000 px, all different: overflows the smallest tier's table
+    labels[70:180, 0:100] = 1          # 11,000 px: overflows the middle tier's
+    labels[0:200, 100:200] = 2         # 20,000 px: the large tier's
+    labels[200:240, 0:60] = 3          # 2,400 px: fits
+    labels[0:70, 300:400] = 4          # flat colours, three sizes
+    labels[70:180, 300:400] = 5
+    labels[0:200, 200:300] = 6         # noise and, from column 300 on, nothing: plain noise
+    dl = torch.from_numpy(labels).cuda().unsqueeze(0)
+    a = _run(ops, torch, lab, dl, 7, k, False, seed=31)
+    b = _run(ops, torch, lab, dl, 7, k, True, seed=31)
+    assert a[5] == 0
+    _same(a, b)
