@@ -1614,6 +1614,9 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
         TIER(8, CAP_LARGE, THREADS_LARGE, MODE_LISTED, 1, 2)
         TIER(8, CAP_SMALL_D, THREADS_SMALL, MODE_LISTED, 2, 1)
         TIER(8, CAP_TINY_D, THREADS_TINY, MODE_LISTED, 3, 0)
+    } else if (dedup) {
+        TIER(16, CAP_LARGE, THREADS_LARGE, MODE_DEDUP, 1, 2)
+        TIER(16, CAP_SMALL_K16, THREADS_SMALL, MODE_DEDUP, 2, 1)
     } else {
         TIER(16, CAP_LARGE, THREADS_LARGE, MODE_LISTED, 1, 2)
         TIER(16, CAP_SMALL_K16, THREADS_SMALL, MODE_LISTED, 2, 1)
