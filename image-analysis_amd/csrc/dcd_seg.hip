@@ -1292,6 +1292,11 @@ __device__ __forceinline__ bool segment_body(
     SEG_MARK(9)
     for (int i = tid; i < (area + 3) / 4; i += THREADS) reinterpret_cast<uint32_t*>(cls)[i] = 0xffffffffu;
     if (tid < KM) largest[tid] = 0;
+    // the cells that need an explicit union below, collected in the accumulators' place
+    uint16_t* joins = reinterpret_cast<uint16_t*>(acc);
+    constexpr int JOINS = KM * ACCW * 64 * 2;
+    int& s_joins = flags[3];
+    if (tid == 0) s_joins = 0;
     __syncthreads();
     SEG_MARK(10)
 #pragma unroll
@@ -1303,9 +1308,13 @@ __device__ __forceinline__ bool segment_body(
     // else NE; all have a smaller index, so the links form a forest) with a plain store.
     // Of the four backward links W / NW / N / NE only one more can be needed: with N present
     // the others follow from the neighbours' own links (NW-N, N-NE, W-N), and W covers NW;
-    // what is left is NE next to a missing N, which is united explicitly below (bit 25).
+    // what is left is NE next to a missing N, which is united explicitly below.  Those cells go
+    // on a list (one LDS atomic per wave and step) that the whole block then works through evenly:
+    // taken where they stand, a wave would run one union after the other for as many steps as any
+    // of its lanes has such a cell, nearly all fourteen.  (Bit 25: no room on the list.)
 #pragma unroll
-    for (int t = 0; t < NPT; ++t)
+    for (int t = 0; t < NPT; ++t) {
+        bool join = false;
         if (keep[t] != 0xffffffffu) {
             const uint32_t cell = keep[t] & 0xffffu;
             const uint8_t c = (uint8_t)(keep[t] >> 16);
@@ -1319,8 +1328,16 @@ __device__ __forceinline__ bool segment_body(
             const bool ne = up && rt && cls[cell - bw + 1] == c;
             // bits 26-28: 0 self, 1 N, 2 W, 3 NW, 4 NE
             keep[t] |= (n_ ? 1u : w_ ? 2u : nw ? 3u : ne ? 4u : 0u) << 26;
-            if (!n_ && (w_ || nw) && ne) keep[t] |= 0x2000000u;
+            join = !n_ && (w_ || nw) && ne;
         }
+        if (join) {
+            const int at = atomicAdd(&s_joins, 1);
+            if (at < JOINS)
+                joins[at] = (uint16_t)(keep[t] & 0xffffu);
+            else
+                keep[t] |= 0x2000000u;
+        }
+    }
     __syncthreads();                                    // every cluster byte has been read
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
@@ -1332,6 +1349,11 @@ __device__ __forceinline__ bool segment_body(
         }
     __syncthreads();
     SEG_MARK(12)
+    for (int e = tid, ne_ = min(s_joins, JOINS); e < ne_; e += THREADS) {
+        const uint32_t cell = joins[e];
+        unite16(par, cell, cell - bw + 1);
+    }
+    if (s_joins > JOINS)
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
         if (keep[t] != 0xffffffffu && (keep[t] & 0x2000000u)) {

@@ -240,3 +240,40 @@ def test_dedup_table_overflow_falls_back_to_the_plain_body():
     b = _run(ops, torch, lab, dl, 7, k, True, seed=31)
     assert a[5] == 0
     _same(a, b)
+
+
+def test_checkerboard_overflows_the_join_list():
+    """Two colours in a checkerboard: every pixel's north neighbour is of the other cluster while
+    its north-east one is of its own, so every cell asks for an explicit union in the coherence
+    pass and the list of such cells overflows in every tier (the rest take the flagged route).
+    Each colour is one 8-connected component.  Gather, lists and the oracle must agree."""
+    torch = _torch()
+    from imgan import ops
+    from oracle import c_oracle
+    H, W, k = 150, 330, 2
+    yy, xx = np.mgrid[0:H, 0:W]
+    labf = np.where(((yy + xx) & 1)[..., None] == 0, np.array([60, 120, 140]),
+                    np.array([180, 130, 100])).astype(np.uint8)
+    lab = torch.from_numpy(labf).cuda().unsqueeze(0)
+    labels = np.full((H, W), -1, dtype=np.int32)
+    labels[0:150, 0:150] = 0           # 22,500 px: the large tier
+    labels[0:100, 150:250] = 1         # 10,000 px: the middle one
+    labels[0:80, 250:330] = 2          # 6,400 px: the smallest
+    dl = torch.from_numpy(labels).cuda().unsqueeze(0)
+    flat = labels.ravel()
+    cen0 = np.zeros((1, 3, k, 3), dtype=np.float32)
+    for s in range(3):
+        idx = np.nonzero(flat == s)[0]
+        cen0[0, s] = labf.reshape(-1, 3)[idx[:2]]
+    a = _run(ops, torch, lab, dl, 3, k, False, cen0=cen0)
+    b = _run(ops, torch, lab, dl, 3, k, True, cen0=cen0)
+    assert a[5] == 0
+    _same(a, b)
+    for s in range(3):
+        idx = np.nonzero(flat == s)[0]
+        rc = np.stack(np.divmod(idx, W), axis=1).astype(np.int32)
+        _, w_cen, w_stats, _ = c_oracle.dcd_segment(labf.reshape(-1, 3)[idx], rc,
+                                                    np.array([0, 1], dtype=np.int32))
+        assert np.array_equal(b[0][0, s].view(np.uint32), w_cen.view(np.uint32)), s
+        assert np.array_equal(b[2][0, s].astype(np.uint64), w_stats), s
+        assert sorted(int(v) for v in w_stats[:, 7]) == [len(idx) // 2, (len(idx) + 1) // 2], s
