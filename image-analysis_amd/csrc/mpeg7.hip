@@ -327,6 +327,14 @@ __device__ __forceinline__ int small_quot(int a, int d) {
     return q + (r >= d) - (r < 0);
 }
 
+// a / d with inv = 1 / (float)d handed in: for 0 <= a < 2^24, 0 < d < 2^24 (a quarter of the
+// instructions of the integer division the compiler expands to)
+__device__ __forceinline__ int quot_inv(int a, int d, float inv) {
+    int q = (int)((float)a * inv);
+    const int r = a - __mul24(q, d);
+    return q + (r >= d) - (r < 0);
+}
+
 __device__ __forceinline__ int hmmd_cell(int b, int g, int r, const HmmdTab& T) {
     int mx = max(max(r, g), b), mn = min(min(r, g), b);
     int d = mx - mn, s2 = mx + mn;
@@ -346,6 +354,32 @@ __device__ __forceinline__ int hmmd_cell(int b, int g, int r, const HmmdTab& T) 
     int ihue = hue * T.nhue[sub] / 360;
     int isum = small_quot((s2 - lo) * T.nsum[sub], 2 * (256 - lo));
     return T.off[sub] + ihue * T.nsum[sub] + isum;
+}
+
+// The same cell with its per-subspace constants and the reciprocals of the two divisors read from
+// LDS tables (region_desc_kernel: the selects from the argument arrays and the two reciprocals were
+// a third of this function's instructions).  rcp2d[d] = 1 / (2 d); sub8[sub] = {lo, nhue, nsum,
+// off, 2 (256 - lo), 1 / that as float bits, -, -}.
+__device__ __forceinline__ int hmmd_cell_tab(int b, int g, int r, const HmmdTab& T,
+                                             const float* rcp2d, const int4* sub8) {
+    const int mx = max(max(r, g), b), mn = min(min(r, g), b);
+    const int d = mx - mn, s2 = mx + mn;
+    int hue = 0;
+    if (d > 0) {
+        int num;
+        if (r == mx) num = 60 * (g - b);
+        else if (g == mx) num = 120 * d + 60 * (b - r);
+        else num = 240 * d + 60 * (r - g);
+        if (num < 0) num += 360 * d;
+        hue = quot_inv(2 * num + d, 2 * d, rcp2d[d]);
+        if (hue >= 360) hue -= 360;
+    }
+    int sub = 0;
+    for (int i = 1; i < T.nsub; ++i) sub += (d >= T.thr[i]);
+    const int4 c0 = sub8[sub * 2], c1 = sub8[sub * 2 + 1];
+    const int ihue = hue * c0.y / 360;
+    const int isum = quot_inv((s2 - c0.x) * c0.z, c1.x, __int_as_float(c1.y));
+    return c0.w + ihue * c0.z + isum;
 }
 
 __global__ __launch_bounds__(256) void hmmd_kernel(const uint8_t* __restrict__ img,
@@ -429,6 +463,10 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
 // "per region".  A box of more than RD_CAP cells is left to the caller (counted in too_big).
 constexpr int RD_THREADS = 512, RD_CAP = 24576, RD_WORDS = RD_CAP / 64;
 constexpr int RD_POOL = 4608;                              // 64-bit words: 36 KB >= RD_CAP grey bytes
+constexpr int RD_TABS = 8, RD_TAB_PITCH = 64 * 4 + 1;
+// edge blocks of a box that fits are 2 or 4 pixels wide, so their sums and squared responses stay
+// far inside 32 bits
+static_assert(RD_CAP / 1100 < 36, "edge blocks wider than 4 pixels need 64-bit responses");
 typedef uint32_t __attribute__((aligned(1))) u32_any;     // one global_load_dword at any address
 static_assert(RD_CAP < 32768, "the colour structure's sub-sampling factor must stay 1 on chip");
 
@@ -447,6 +485,19 @@ __device__ __forceinline__ unsigned long long bits_at(const unsigned long long* 
     return bs ? (lo >> bs) | (hi << (64 - bs)) : lo;
 }
 
+#ifdef IMGAN_RD_TIMING
+// phase clocks of thread 0, summed over blocks (tools/rd_timing.py; never built into the product)
+__device__ unsigned long long rd_timing[16];
+#define RD_MARK(i)                                                          \
+    if (tid == 0) {                                                         \
+        unsigned long long now_ = wall_clock64();                           \
+        atomicAdd(&rd_timing[i], now_ - t_last_);                           \
+        t_last_ = now_;                                                     \
+    }
+#else
+#define RD_MARK(i)
+#endif
+
 __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     const uint8_t* __restrict__ img, const int32_t* __restrict__ labels, const int32_t* __restrict__ bbox,
     int H, int W, int nseg, int nbins, HmmdTab T, unsigned long long* __restrict__ cld_sums,
@@ -457,8 +508,13 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     __shared__ unsigned long long pool[RD_POOL];
     __shared__ uint8_t col[RD_CAP];
     __shared__ unsigned long long member[RD_WORDS], fits[RD_WORDS];
-    __shared__ uint32_t tab[64 * 4], hist[256], ehd[96], present[8], cnts[264];
+    // grid sums in RD_TABS copies (a cell adds to copy = lane % RD_TABS; the copies start one bank
+    // apart): the 64 cells of a wave fall into a handful of blocks, and lanes that add to the
+    // same word take turns
+    __shared__ uint32_t tab[RD_TABS * RD_TAB_PITCH], hist[256], ehd[96], present[8], cnts[264];
     __shared__ uint8_t slot_of[256], colour_of[257];
+    __shared__ float rcp2d[256];
+    __shared__ int4 sub8[5 * 2];
     uint8_t* gray = reinterpret_cast<uint8_t*>(pool);
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const size_t gs = (size_t)b * nseg + s;
@@ -478,22 +534,31 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
         return;
     }
     const int area = (int)area_ll, nwords = (area + 63) >> 6;
-    for (int i = tid; i < 64 * 4; i += RD_THREADS) tab[i] = 0;
+#ifdef IMGAN_RD_TIMING
+    unsigned long long t_last_ = wall_clock64();
+#endif
+    for (int i = tid; i < RD_TABS * RD_TAB_PITCH; i += RD_THREADS) tab[i] = 0;
     for (int i = tid; i < 256; i += RD_THREADS) hist[i] = 0;
     for (int i = tid; i < 96; i += RD_THREADS) ehd[i] = 0;
     if (tid < 8) present[tid] = 0;
+    if (tid < 256) rcp2d[tid] = 1.0f / (float)(2 * max(tid, 1));
+    if (tid < T.nsub) {
+        const int lo = T.thr[tid], den = 2 * (256 - lo);
+        sub8[tid * 2] = make_int4(lo, T.nhue[tid], T.nsum[tid], T.off[tid]);
+        sub8[tid * 2 + 1] = make_int4(den, __float_as_int(1.0f / (float)den), 0, 0);
+    }
     __syncthreads();
 
     // ---- stage the box; 8 x 8 grid sums of the region's pixels on the way
     const uint8_t* im = img + (size_t)b * H * W * 3;
     const int32_t* lab = labels + (size_t)b * H * W;
-    const float inv_bw = 1.0f / (float)bw;
+    const float inv_bw = 1.0f / (float)bw, inv_bh = 1.0f / (float)bh;
     // Four cells per thread and step, every load issued before the first use (a step is bound by
     // the memory latency of its loads, not by their number); addresses are clamped into the box
     // instead of branched around, and the three colour bytes come with one unaligned dword load
     // (the very last pixel of the batch is read one byte early so that the load stays in bounds).
     constexpr int GU = 4;
-    const size_t last_px = (size_t)gridDim.y * H * W - 1;
+    const uint32_t last_p = b == (int)gridDim.y - 1 ? (uint32_t)H * (uint32_t)W - 1u : 0xffffffffu;
     for (int i0 = 0; i0 < area; i0 += RD_THREADS * GU) {
         int xx[GU], yy[GU], lbl[GU];
         uint32_t raw[GU], sh[GU];
@@ -501,16 +566,14 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
         for (int u = 0; u < GU; ++u) {
             const int i = i0 + u * RD_THREADS + tid;
             const int ic = i < area ? i : area - 1;
-            int y = (int)((float)ic * inv_bw);
-            int x = ic - y * bw;
-            y += (x >= bw) - (x < 0);                    // the float quotient can be off by one
-            x = ic - y * bw;
+            const int y = quot_inv(ic, bw, inv_bw);      // cells < 2^15
+            const int x = ic - __mul24(y, bw);
             xx[u] = x, yy[u] = y;
-            const size_t p = (size_t)(y0 + y) * W + (x0 + x);
+            // 32-bit offsets inside the image (H * W * 3 < 2^32, checked by the host)
+            const uint32_t p = (uint32_t)__mul24(y0 + y, W) + (uint32_t)(x0 + x);
             lbl[u] = lab[p];
-            const size_t gp = (size_t)b * H * W + p;
-            sh[u] = gp == last_px ? 1u : 0u;
-            raw[u] = *reinterpret_cast<const u32_any*>(im + p * 3 - sh[u]);
+            sh[u] = p == last_p ? 1u : 0u;
+            raw[u] = *reinterpret_cast<const u32_any*>(im + (p * 3u - sh[u]));
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
@@ -523,25 +586,32 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
             if (live) gray[i] = (uint8_t)gray_px(cb, cg, cr);
             int blk = -1;
             if (mem) {
-                const uint32_t c = (uint32_t)hmmd_cell((int)cb, (int)cg, (int)cr, T);
+                const uint32_t c = (uint32_t)hmmd_cell_tab((int)cb, (int)cg, (int)cr, T, rcp2d, sub8);
                 col[i] = (uint8_t)c;
                 if (!((present[c >> 5] >> (c & 31u)) & 1u)) atomicOr(&present[c >> 5], 1u << (c & 31u));
-                blk = ((yy[u] * 8) / bh) * 8 + (xx[u] * 8) / bw;
+                blk = quot_inv(yy[u] * 8, bh, inv_bh) * 8 + quot_inv(xx[u] * 8, bw, inv_bw);
             }
             // (one wave-wide sum per block and field instead of these atomics, 64 cells hitting a
             // handful of LDS words, was measured slower: 10.1 against 7.2 ms on the mosaic)
             if (blk >= 0) {
-                atomicAdd(&tab[blk * 4], cb);
-                atomicAdd(&tab[blk * 4 + 1], cg);
-                atomicAdd(&tab[blk * 4 + 2], cr);
-                atomicAdd(&tab[blk * 4 + 3], 1u);
+                uint32_t* t4 = tab + (lane & (RD_TABS - 1)) * RD_TAB_PITCH + blk * 4;
+                atomicAdd(t4, cb);
+                atomicAdd(t4 + 1, cg);
+                atomicAdd(t4 + 2, cr);
+                atomicAdd(t4 + 3, 1u);
             }
             const unsigned long long mbits = __ballot(mem), fbits = __ballot(fit);   // 64 consecutive cells
             if (lane == 0 && live) member[i >> 6] = mbits, fits[i >> 6] = fbits;
         }
     }
     __syncthreads();
-    for (int i = tid; i < 64 * 4; i += RD_THREADS) csum[i] = tab[i];
+    RD_MARK(0)
+    for (int i = tid; i < 64 * 4; i += RD_THREADS) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int c = 0; c < RD_TABS; ++c) sum += tab[c * RD_TAB_PITCH + i];
+        csum[i] = sum;
+    }
     auto is_member = [&](int cell) { return (member[cell >> 6] >> (cell & 63)) & 1ull; };
 
     // ---- edge histogram: blocks tile the box from its corner; a block votes if the region holds
@@ -549,32 +619,33 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     {
         const int bs = ehd_block_size_dev(bh, bw), hb = bs >> 1;
         const int nbx = bw / bs, nby = bh / bs;
+        const float inv_nbx = 1.0f / (float)max(nbx, 1);
         for (int k = tid; k < nbx * nby; k += RD_THREADS) {
-            const int by = k / nbx, bx = k - by * nbx;
-            long long s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+            const int by = quot_inv(k, nbx, inv_nbx), bx = k - by * nbx;
+            int s1 = 0, s2 = 0, s3 = 0, s4 = 0;
             bool all = true;
             for (int j = 0; j < bs; ++j)
                 for (int i = 0; i < bs; ++i) {
                     const int cell = (by * bs + j) * bw + bx * bs + i;
                     all = all && is_member(cell);
-                    const long long g = gray[cell];
+                    const int g = gray[cell];
                     s1 += (j < hb && i < hb) ? g : 0;
                     s2 += (j < hb && i >= hb) ? g : 0;
                     s3 += (j >= hb && i < hb) ? g : 0;
                     s4 += (j >= hb && i >= hb) ? g : 0;
                 }
             if (!all) continue;
-            const long long v = s1 - s2 + s3 - s4, h = s1 + s2 - s3 - s4, d45 = s1 - s4, d135 = s2 - s3,
-                            nd = s1 - s2 - s3 + s4;
-            const long long e[5] = {v * v, h * h, 2 * d45 * d45, 2 * d135 * d135, 4 * nd * nd};
-            long long best = e[0];
+            const int v = s1 - s2 + s3 - s4, h = s1 + s2 - s3 - s4, d45 = s1 - s4, d135 = s2 - s3,
+                      nd = s1 - s2 - s3 + s4;
+            const int e[5] = {v * v, h * h, 2 * d45 * d45, 2 * d135 * d135, 4 * nd * nd};
+            int best = e[0];
             int type = 0;
 #pragma unroll
             for (int t = 1; t < 5; ++t)
                 if (e[t] > best) best = e[t], type = t;
-            const int sub = (bx * bs * 4) / bw + ((by * bs * 4) / bh) * 4;
+            const int sub = quot_inv(bx * bs * 4, bw, inv_bw) + quot_inv(by * bs * 4, bh, inv_bh) * 4;
             atomicAdd(&ehd[80 + sub], 1u);
-            const long long thr = 11ll * hb * hb;
+            const int thr = 11 * hb * hb;
             if (best >= thr * thr) atomicAdd(&ehd[sub * 5 + type], 1u);
         }
     }
@@ -588,6 +659,7 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     // a pass takes as many slots as the pool holds bitmaps for (all of them for a typical
     // superpixel).
     uint32_t nwin = 0;
+    RD_MARK(1)
     if (bw >= 8 && bh >= 8) {
         if (tid < 256) {
             const uint32_t c = (uint32_t)tid;
@@ -601,7 +673,9 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
         int nslots = 1;
         for (int w = 0; w < 8; ++w) nslots += __popc(present[w]);
         const int G = min(nslots, RD_POOL / (2 * nwords));     // >= 6
+        const float inv_nw = 1.0f / (float)nwords;
         __syncthreads();                                      // the edge histogram is done with `gray`
+        RD_MARK(2)
         for (int g0 = 0; g0 < nslots; g0 += G) {
             const int ng = min(G, nslots - g0);
             unsigned long long* Rb = pool;
@@ -609,33 +683,50 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
             for (int k = tid; k < ng * nwords; k += RD_THREADS) Rb[k] = 0ull;
             for (int k = tid; k < ng; k += RD_THREADS) cnts[k] = 0;
             __syncthreads();
+            RD_MARK(3)
             // a wave owns the 64-bit word of its 64 consecutive cells: one ballot and one plain
             // store per slot that occurs among them
-            for (int i0 = 0; i0 < area; i0 += RD_THREADS) {
-                const int i = i0 + tid;
-                int r = -1;
-                const bool mem = i < area && is_member(i);
-                if (mem) {
-                    int sl = slot_of[col[i]];
-                    if (sl == 0) sl = 256;                   // slot 256 is stored as 0 in the byte table
-                    r = sl - g0;
-                    if (r >= ng) r = -1;
+            // (four words per wave and step: the two dependent table reads of a step overlap)
+            constexpr int BU = 4;
+            for (int i0 = 0; i0 < area; i0 += RD_THREADS * BU) {
+                int rr[BU];
+                bool mm[BU];
+                uint8_t cc[BU];
+#pragma unroll
+                for (int u = 0; u < BU; ++u) {
+                    const int i = i0 + u * RD_THREADS + tid;
+                    mm[u] = i < area && is_member(i);
+                    cc[u] = col[min(i, area - 1)];           // not a member: any byte
                 }
-                if (g0 == 0) {
-                    const unsigned long long all = __ballot(mem);
-                    if (lane == 0 && i < area) Rb[i >> 6] = all;
-                }
-                unsigned long long todo = __ballot(r >= 0);
-                while (todo) {
-                    const int rsel = __builtin_amdgcn_readlane(r, __ffsll((long long)todo) - 1);
-                    const unsigned long long who = __ballot(r == rsel);
-                    if (lane == 0) Rb[(size_t)rsel * nwords + (i >> 6)] = who;
-                    todo &= ~who;
+#pragma unroll
+                for (int u = 0; u < BU; ++u) rr[u] = slot_of[cc[u]];
+#pragma unroll
+                for (int u = 0; u < BU; ++u) {
+                    const int i = i0 + u * RD_THREADS + tid;
+                    int r = -1;
+                    if (mm[u]) {
+                        int sl = rr[u];
+                        if (sl == 0) sl = 256;               // slot 256 is stored as 0 in the byte table
+                        r = sl - g0;
+                        if (r >= ng) r = -1;
+                    }
+                    if (g0 == 0) {
+                        const unsigned long long all = __ballot(mm[u]);
+                        if (lane == 0 && i < area) Rb[i >> 6] = all;
+                    }
+                    unsigned long long todo = __ballot(r >= 0);
+                    while (todo) {
+                        const int rsel = __builtin_amdgcn_readlane(r, __ffsll((long long)todo) - 1);
+                        const unsigned long long who = __ballot(r == rsel);
+                        if (lane == 0) Rb[(size_t)rsel * nwords + (i >> 6)] = who;
+                        todo &= ~who;
+                    }
                 }
             }
             __syncthreads();
+            RD_MARK(4)
             for (int k = tid; k < ng * nwords; k += RD_THREADS) {
-                const int r = k / nwords, w = k - r * nwords;
+                const int r = quot_inv(k, nwords, inv_nw), w = k - r * nwords;
                 const unsigned long long* Rr = Rb + (size_t)r * nwords;
                 const unsigned long long p = Rr[w], n = w + 1 < nwords ? Rr[w + 1] : 0ull;
                 unsigned long long d = p;
@@ -644,8 +735,9 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
                 Db[k] = d;
             }
             __syncthreads();
+            RD_MARK(5)
             for (int k = tid; k < ng * nwords; k += RD_THREADS) {
-                const int r = k / nwords, w = k - r * nwords;
+                const int r = quot_inv(k, nwords, inv_nw), w = k - r * nwords;
                 const unsigned long long* Dr = Db + (size_t)r * nwords;
                 unsigned long long v = Dr[w];
 #pragma unroll
@@ -654,18 +746,24 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
                 if (c) atomicAdd(&cnts[r], c);
             }
             __syncthreads();
+            RD_MARK(6)
             for (int r = tid; r < ng; r += RD_THREADS) {
                 const int sl = g0 + r;
                 if (sl == 0) nwin = cnts[r];                   // thread 0 of the first pass
                 else hist[colour_of[sl]] = cnts[r];
             }
             __syncthreads();                                   // cnts and the pool are reused
+            RD_MARK(7)
+#ifdef IMGAN_RD_TIMING
+            if (tid == 0) atomicAdd(&rd_timing[15], 1ull);
+#endif
         }
     }
     __syncthreads();
     for (int i = tid; i < 96; i += RD_THREADS) eo[i] = (int32_t)ehd[i];
     for (int i = tid; i < nbins; i += RD_THREADS) co[i] = (int32_t)hist[i];
     if (tid == 0) co[nbins] = (int32_t)nwin;
+    RD_MARK(8)
 }
 
 int make_hmmd(int nbins, HmmdTab* T) {
@@ -840,6 +938,18 @@ extern "C" int imgan_csd(const uint8_t* bgr, int B, int H, int W, int nbins, int
     return imgan::check_launch("imgan_csd");
 }
 
+#ifdef IMGAN_RD_TIMING
+extern "C" int imgan_debug_rd_timing(unsigned long long* out16, int reset) {
+    IMGAN_HIP(hipDeviceSynchronize());
+    IMGAN_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(rd_timing), 128));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        IMGAN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rd_timing), z, 128));
+    }
+    return 0;
+}
+#endif
+
 extern "C" size_t imgan_region_descriptors_scratch_bytes(int B, int nseg) {
     return B < 1 || nseg < 1 ? 0 : (size_t)B * nseg * 64 * 4 * 8;
 }
@@ -853,6 +963,8 @@ extern "C" int imgan_region_descriptors(const uint8_t* bgr, const int32_t* label
     IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535,
                   "imgan_region_descriptors: bad shape");
     IMGAN_REQUIRE((long long)B * nseg * 3 < 0x7fffffffLL, "imgan_region_descriptors: too many regions");
+    IMGAN_REQUIRE((long long)H * W * 3 < 0x100000000LL && W < (1 << 23) && H < (1 << 23),
+                  "imgan_region_descriptors: image too large (H * W * 3 must stay below 2^32)");
     HmmdTab T;
     if (int rc = make_hmmd(nbins, &T)) return rc;
     hipStream_t st = (hipStream_t)stream;

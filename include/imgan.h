@@ -330,6 +330,7 @@ int imgan_hmmd_quantise(const uint8_t* bgr, uint8_t* out, int64_t npix, int nbin
  * [B][nseg][96], csd_out int32 [B][nseg][nbins+1].  A region whose box has more than 24,576 cells
  * does not fit on chip: its rows are zeroed and it is counted in too_big_out (device int32); such
  * regions (merged regions, whole frames) take the whole-image entry points on their crop.
+ * One image holds at most 2^32 / 3 pixels (32-bit offsets inside an image; larger: error).
  * scratch: imgan_region_descriptors_scratch_bytes(B, nseg) bytes. */
 size_t imgan_region_descriptors_scratch_bytes(int B, int nseg);
 int imgan_region_descriptors(const uint8_t* bgr, const int32_t* labels, const int32_t* bbox, int B,

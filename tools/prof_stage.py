@@ -1,5 +1,5 @@
 """Runs one stage of the path on a synthetic batch (for rocprofv3 counter passes).
-usage: python3 tools/prof_stage.py {slic|dcd|desc|all} [B]"""
+usage: python3 tools/prof_stage.py {slic|dcd|desc|all|rag4k|mosaic} [B]"""
 import os
 import sys
 
@@ -21,6 +21,14 @@ if stage == "rag4k":                       # configs[2]: 4 x 3840x2160, K = 2000
         rp.step(bgr, check=False)
     torch.cuda.synchronize()
     print("done", stage, B)
+    sys.exit(0)
+if stage == "mosaic":                      # configs[4] geometry on a 4096^2 crop: S = 73, per-region descriptors
+    bgr = synth_batch(1, 4096, 4096, 3125, 99, "cuda")
+    mp = FullPipeline(1, 4096, 4096, 3125, per_region=True)
+    for rep in range(2):
+        mp.step(bgr)
+    torch.cuda.synchronize()
+    print("done", stage)
     sys.exit(0)
 bgr = synth_batch(B, 1080, 1920, 400, 1234, "cuda")
 pipe = FullPipeline(B, 1080, 1920, 400)
