@@ -43,10 +43,13 @@ __device__ __forceinline__ uint32_t hash64(unsigned long long k) {
     return (uint32_t)k;
 }
 
-__device__ void edge_insert(unsigned long long* tab, unsigned long long mask, int a, int b,
+__device__ __forceinline__ unsigned long long edge_key(int a, int b) {
+    const int u = min(a, b), v = max(a, b);
+    return ((unsigned long long)(u + 1) << 32) | (unsigned long long)(v + 1);
+}
+
+__device__ void edge_insert(unsigned long long* tab, unsigned long long mask, unsigned long long key,
                             int* overflow) {
-    int u = min(a, b), v = max(a, b);
-    unsigned long long key = ((unsigned long long)(u + 1) << 32) | (unsigned long long)(v + 1);
     unsigned long long h = hash64(key) & mask;
     for (unsigned long long probe = 0; probe <= mask; ++probe) {
         unsigned long long cur = tab[h];
@@ -62,13 +65,24 @@ __device__ void edge_insert(unsigned long long* tab, unsigned long long mask, in
 
 typedef uint32_t __attribute__((aligned(1))) u32_any;   // one global_load_dword at any address
 constexpr int RAG_ROWS = 16;
+constexpr int RAG_PEND = 512;      // pairs a block parks in LDS before they go to the table
 
-// one lane per column; block = 256 columns x RAG_ROWS rows (grid: column strips, row strips, images)
+// one lane per column; block = 256 columns x RAG_ROWS rows (grid: column strips, row strips, images).
+// SUMS == false: adjacency only, the image is not read (the caller has the per-label sums already,
+// e.g. from the last SLIC round: imgan_slic_label_sums).
+template <bool SUMS>
 __global__ __launch_bounds__(256) void rag_accumulate_kernel(
     const uint8_t* __restrict__ img, const int32_t* __restrict__ labels, int H, int W, int K,
     unsigned long long* __restrict__ sums, unsigned long long* __restrict__ edges,
     unsigned long long edge_mask, int* __restrict__ overflow, long long last_px) {
+    // The pairs a block meets are parked in LDS and go to the table together when its rows are
+    // done: looked up where they are met, the one lane with a new pair holds its wave's row loop
+    // up for a round trip to the table in global memory.
+    __shared__ unsigned long long pend[RAG_PEND];
+    __shared__ int npend;
     const int b = blockIdx.z;
+    if (threadIdx.x == 0) npend = 0;
+    __syncthreads();
     const long long npix = (long long)H * W;
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int32_t* lab = labels + (size_t)b * npix;
@@ -82,6 +96,14 @@ __global__ __launch_bounds__(256) void rag_accumulate_kernel(
     // added up over the wave and leave with one atomic per field, as do all sums at the end.
     int cur = -1;
     uint32_t a0 = 0, a1 = 0, a2 = 0, an = 0;
+    auto park = [&](int u, int v) {
+        const unsigned long long key = edge_key(u, v);
+        const int at = atomicAdd(&npend, 1);
+        if (at < RAG_PEND)
+            pend[at] = key;
+        else
+            edge_insert(E, edge_mask, key, overflow + b);
+    };
     auto flush = [&](bool who) {
         int pending = (who && cur >= 0 && cur < K) ? cur : -1;
         while (true) {
@@ -145,27 +167,29 @@ __global__ __launch_bounds__(256) void rag_accumulate_kernel(
         sides(above, pcl, pcr);
     }
     // one row ahead: the loads of row y + 1 are in flight while row y is worked on
-    RowIn next = fetch(ystart, true);
+    RowIn next = fetch(ystart, SUMS);
     for (int y = ystart; y < yend; ++y) {
     const RowIn here = next;
-    if (y + 1 < yend) next = fetch(y + 1, true);
+    if (y + 1 < yend) next = fetch(y + 1, SUMS);
     const int l = here.c;
     const uint32_t raw = here.raw;
     int cl = -1, cr = -1;
     if (E) sides(here, cl, cr);
-    const bool chg = (l != cur);
-    if (__ballot(chg) != 0ull) {                           // wave uniform
-        flush(chg);
-        if (chg) {
-            cur = l;
-            a0 = a1 = a2 = an = 0;
+    if (SUMS) {
+        const bool chg = (l != cur);
+        if (__ballot(chg) != 0ull) {                       // wave uniform
+            flush(chg);
+            if (chg) {
+                cur = l;
+                a0 = a1 = a2 = an = 0;
+            }
         }
-    }
-    if (l >= 0) {
-        a0 += raw & 0xffu;
-        a1 += (raw >> 8) & 0xffu;
-        a2 += (raw >> 16) & 0xffu;
-        an += 1u;
+        if (l >= 0) {
+            a0 += raw & 0xffu;
+            a1 += (raw >> 8) & 0xffu;
+            a2 += (raw >> 16) & 0xffu;
+            an += 1u;
+        }
     }
     // ---- adjacency: W, N, NW, NE neighbours (each unordered 8-neighbour pair once).  A border
     // runs on for many pixels: a pair this lane met in the row above (vertical border) or the lane
@@ -173,17 +197,22 @@ __global__ __launch_bounds__(256) void rag_accumulate_kernel(
     if (E) {
         if (l >= 0) {
             const bool w_ = cl >= 0 && cl != l && !(l == pc && cl == pcl);
-            if (w_) edge_insert(E, edge_mask, l, cl, overflow + b);
+            if (w_) park(l, cl);
             const bool n_ = pc >= 0 && pc != l && pc != cl && !(lane > 0 && cl == l && pcl == pc);
-            if (n_) edge_insert(E, edge_mask, l, pc, overflow + b);
-            if (pcl >= 0 && pcl != l && pcl != cl && pcl != pc) edge_insert(E, edge_mask, l, pcl, overflow + b);
+            if (n_) park(l, pc);
+            if (pcl >= 0 && pcl != l && pcl != cl && pcl != pc) park(l, pcl);
             if (pcr >= 0 && pcr != l && pcr != cl && pcr != pc && pcr != pcl)
-                edge_insert(E, edge_mask, l, pcr, overflow + b);
+                park(l, pcr);
         }
         pc = l, pcl = cl, pcr = cr;
     }
     }
-    flush(true);
+    if (SUMS) flush(true);
+    if (E) {
+        __syncthreads();
+        const int np = min(npend, RAG_PEND);
+        for (int i = threadIdx.x; i < np; i += 256) edge_insert(E, edge_mask, pend[i], overflow + b);
+    }
 }
 
 __global__ __launch_bounds__(256) void relabel_kernel(const int32_t* __restrict__ labels,
@@ -198,6 +227,38 @@ __global__ __launch_bounds__(256) void relabel_kernel(const int32_t* __restrict_
          p += (long long)gridDim.x * 256) {
         int l = src[p];
         dst[p] = (l >= 0 && l < K) ? L[l] : 0;
+    }
+}
+
+// Four labels per lane and step (16-byte loads and stores), the table in LDS.  Needs npix % 4 == 0
+// (every image of the batch then starts on a 16-byte boundary if the first one does) and
+// K <= RELABEL_LDS_K.
+constexpr int RELABEL_LDS_K = 8192;
+__global__ __launch_bounds__(256) void relabel4_kernel(const int32_t* __restrict__ labels,
+                                                       const int32_t* __restrict__ lut,
+                                                       int32_t* __restrict__ out, long long nquad,
+                                                       int K) {
+    __shared__ int32_t T[RELABEL_LDS_K];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < K; i += 256) T[i] = lut[(size_t)b * K + i];
+    __syncthreads();
+    const int4* src = reinterpret_cast<const int4*>(labels) + (size_t)b * nquad;
+    int4* dst = reinterpret_cast<int4*>(out) + (size_t)b * nquad;
+    auto map = [&](int l) { return ((unsigned)l < (unsigned)K) ? T[l] : 0; };
+    constexpr int U = 2;                                 // loads in flight per lane
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long q0 = (long long)blockIdx.x * 256 + threadIdx.x; q0 < nquad; q0 += stride * U) {
+        int4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long q = q0 + u * stride;
+            v[u] = src[q < nquad ? q : nquad - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long q = q0 + u * stride;
+            if (q < nquad) dst[q] = make_int4(map(v[u].x), map(v[u].y), map(v[u].z), map(v[u].w));
+        }
     }
 }
 
@@ -259,7 +320,8 @@ struct Sets {
 extern "C" int imgan_rag_accumulate(const uint8_t* img, const int32_t* labels, int B, int H, int W,
                                     int K, uint64_t* sums, uint64_t* edges, int64_t edge_cap,
                                     int32_t* overflow, imgan_stream_t stream) {
-    IMGAN_REQUIRE(img && labels && sums, "imgan_rag_accumulate: null pointer");
+    IMGAN_REQUIRE(labels && ((img && sums) || (!img && !sums && edges)),
+                  "imgan_rag_accumulate: null pointer (image and sums go together; without them the edge table is required)");
     IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && K >= 1, "imgan_rag_accumulate: bad shape");
     IMGAN_REQUIRE(B <= 65535, "imgan_rag_accumulate: batch > 65535, split the call");
     if (edges) {
@@ -270,10 +332,15 @@ extern "C" int imgan_rag_accumulate(const uint8_t* img, const int32_t* labels, i
     IMGAN_REQUIRE(H <= 65535 * RAG_ROWS, "imgan_rag_accumulate: too many rows");
     IMGAN_REQUIRE((long long)B * H * W >= 2, "imgan_rag_accumulate: needs at least two pixels");
     dim3 grid((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, RAG_ROWS), (unsigned)B);
-    hipLaunchKernelGGL(rag_accumulate_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, labels,
-                       H, W, K, (unsigned long long*)sums, (unsigned long long*)edges,
-                       (unsigned long long)(edges ? edge_cap - 1 : 0), overflow,
-                       (long long)B * H * W - 1);
+    if (img)
+        hipLaunchKernelGGL(rag_accumulate_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, img,
+                           labels, H, W, K, (unsigned long long*)sums, (unsigned long long*)edges,
+                           (unsigned long long)(edges ? edge_cap - 1 : 0), overflow,
+                           (long long)B * H * W - 1);
+    else
+        hipLaunchKernelGGL(rag_accumulate_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, img,
+                           labels, H, W, K, (unsigned long long*)sums, (unsigned long long*)edges,
+                           (unsigned long long)(edge_cap - 1), overflow, (long long)B * H * W - 1);
     return imgan::check_launch("rag_accumulate_kernel");
 }
 
@@ -281,6 +348,15 @@ extern "C" int imgan_relabel_lut(const int32_t* labels, const int32_t* lut, int3
                                  int64_t npix, int K, imgan_stream_t stream) {
     IMGAN_REQUIRE(labels && lut && out, "imgan_relabel_lut: null pointer");
     IMGAN_REQUIRE(B >= 1 && npix >= 1 && K >= 1 && B <= 65535, "imgan_relabel_lut: bad shape");
+    if (npix % 4 == 0 && K <= RELABEL_LDS_K && ((uintptr_t)labels & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+        const int64_t nquad = npix / 4;
+        // enough blocks per image to fill the chip, few enough that the table load stays small
+        // beside the 16 KB of labels a block of 256 lanes moves per step
+        dim3 grid4((unsigned)std::min<int64_t>(imgan::cdiv(nquad, 256 * 8), 4096), (unsigned)B);
+        hipLaunchKernelGGL(relabel4_kernel, grid4, dim3(256), 0, (hipStream_t)stream, labels, lut, out,
+                           (long long)nquad, K);
+        return imgan::check_launch("relabel4_kernel");
+    }
     dim3 grid((unsigned)std::min<int64_t>(imgan::cdiv(npix, 256), 8192), (unsigned)B);
     hipLaunchKernelGGL(relabel_kernel, grid, dim3(256), 0, (hipStream_t)stream, labels, lut, out,
                        (long long)npix, K);

@@ -969,6 +969,22 @@ __global__ void slic_counts_kernel(int32_t* __restrict__ counts, Ws w, int total
     if (t < total) counts[t] = (int32_t)w.sums[(size_t)t * NFIELD + 5];
 }
 
+// per-label {sum L, sum a, sum b, count} of the last round, in the layout of imgan_rag_accumulate
+// ([B][K][4]; labels n..K-1 do not occur: zero)
+__global__ void slic_label_sums_kernel(unsigned long long* __restrict__ out, Ws w, int n, int K,
+                                       int total) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int b = t / K, s = t - b * K;
+    unsigned long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    if (s < n) {
+        const unsigned long long* src = w.sums + ((size_t)b * n + s) * NFIELD;
+        v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[5];
+    }
+    unsigned long long* dst = out + (size_t)t * 4;
+    dst[0] = v0, dst[1] = v1, dst[2] = v2, dst[3] = v3;
+}
+
 // 0: 32-bit key, 1: u64 key, 2: literal float64 (non-integral colour weight).  *rel: the
 // 32-bit key also fits a signed word once its per-pixel constant is dropped.
 int key_mode(int S, double cw, bool* rel) {
@@ -1209,6 +1225,17 @@ extern "C" int imgan_slic_label_counts(int B, int H, int W, int S, int n, const 
     hipLaunchKernelGGL(slic_counts_kernel, dim3(imgan::cdiv(B * n, 256)), dim3(256), 0,
                        (hipStream_t)stream, counts, w, B * n);
     return imgan::check_launch("slic_counts_kernel");
+}
+
+extern "C" int imgan_slic_label_sums(int B, int H, int W, int S, int n, const void* workspace, int K,
+                                     uint64_t* sums, imgan_stream_t stream) {
+    IMGAN_REQUIRE(sums && workspace, "imgan_slic_label_sums: null pointer");
+    IMGAN_REQUIRE(K >= 1 && (long long)B * K < 0x7fffffffLL, "imgan_slic_label_sums: bad label count");
+    if (int rc = validate("imgan_slic_label_sums", B, H, W, S, n)) return rc;
+    Ws w = bind(const_cast<void*>(workspace), make_layout(B, H, W, S, n));
+    hipLaunchKernelGGL(slic_label_sums_kernel, dim3(imgan::cdiv(B * K, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (unsigned long long*)sums, w, n, K, B * K);
+    return imgan::check_launch("slic_label_sums_kernel");
 }
 
 extern "C" int imgan_slic_run(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,

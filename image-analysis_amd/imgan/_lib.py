@@ -44,6 +44,8 @@ SIGNATURES = {
                                             c_void_p]),
     "imgan_slic_label_counts": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p]),
+    "imgan_slic_label_sums": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                      c_void_p]),
     "imgan_slic_run": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "imgan_rag_accumulate": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,

@@ -184,6 +184,16 @@ class SlicPlan(object):
                                           _ptr(self.workspace), _ptr(out), _stream()))
         return out
 
+    def label_sums(self, out):
+        """out int64 [B,K,4] = sum L, sum a, sum b, count per label after the last round (rows
+        n..K-1 zero): rag_accumulate's sums for the image SLIC ran on, without another pass."""
+        _dev(out, torch.int64, "out")
+        if out.dim() != 3 or out.shape[0] != self.B or out.shape[2] != 4 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous [B, K, 4] tensor")
+        check(lib.imgan_slic_label_sums(self.B, self.H, self.W, self.S, self.n, _ptr(self.workspace),
+                                        int(out.shape[1]), _ptr(out), _stream()))
+        return out
+
     def run(self, lab, colour_weight, num_iter):
         """SLICSuperPixel.run() (slic.py:78-127); returns (labels, centres) device tensors."""
         lab = self._check(lab)
@@ -266,19 +276,28 @@ class RagPlan(object):
         self.lut = torch.zeros((self.B, self.K), dtype=torch.int32, device=dev)
         self.status = torch.zeros(self.B, dtype=torch.int32, device=dev)
 
-    def run(self, img, labels, c_factor):
+    def run(self, img, labels, c_factor, slic=None):
         """img u8 [B,H,W,3], labels int32 [B,H,W] -> (lut int32 [B,K], status int32 [B]), both on
-        the device, enqueued on the current stream."""
+        the device, enqueued on the current stream.  slic: the SlicPlan whose last round produced
+        `labels` from `img` -- its sums are the per-label sums (rag_segmentation.py:38-48 on the
+        image of run_slic :21-25), and only the adjacency pass over the labels is left."""
         img = as_batch(_dev(img, torch.uint8, "img"))
         _dev(labels, torch.int32, "labels")
         B, H, W, _ = img.shape
         if B != self.B or tuple(labels.shape) != (B, H, W):
             raise ValueError("batch does not match the plan")
-        self.sums.zero_()
         self.table.zero_()
         self.overflow.zero_()
-        check(lib.imgan_rag_accumulate(_ptr(img), _ptr(labels), B, H, W, self.K, _ptr(self.sums),
-                                       _ptr(self.table), self.cap, _ptr(self.overflow), _stream()))
+        if slic is not None:
+            if (slic.B, slic.H, slic.W) != (B, H, W) or slic.n > self.K:
+                raise ValueError("SLIC plan does not match the batch")
+            slic.label_sums(self.sums)
+            check(lib.imgan_rag_accumulate(None, _ptr(labels), B, H, W, self.K, None,
+                                           _ptr(self.table), self.cap, _ptr(self.overflow), _stream()))
+        else:
+            self.sums.zero_()
+            check(lib.imgan_rag_accumulate(_ptr(img), _ptr(labels), B, H, W, self.K, _ptr(self.sums),
+                                           _ptr(self.table), self.cap, _ptr(self.overflow), _stream()))
         check(lib.imgan_rag_merge_device(_ptr(self.sums), _ptr(self.table), self.cap,
                                          _ptr(self.overflow), B, self.K, float(c_factor),
                                          _ptr(self.lut), _ptr(self.status), _stream()))

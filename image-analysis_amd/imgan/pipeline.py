@@ -180,7 +180,7 @@ class RagPipeline(object):
         labels = self.slic.labels
         if self.rag is not None:
             luts, _ = self._timed("rag_accumulate+merge", timed,
-                                  lambda: self.rag.run(self.lab, labels, self.c_factor))
+                                  lambda: self.rag.run(self.lab, labels, self.c_factor, slic=self.slic))
             if check:
                 self.redone += self.rag.finish(self.lab, labels, self.c_factor)
         else:                                   # more labels than the device merge holds in LDS

@@ -119,6 +119,13 @@ int imgan_slic_finalise_centres(int32_t* centres, int B, int H, int W, int S, in
 int imgan_slic_label_counts(int B, int H, int W, int S, int n, const void* workspace,
                             int32_t* counts, imgan_stream_t stream);
 
+/* sums uint64 [B][K][4] = sum L, sum a, sum b, count per label after the last
+ * imgan_slic_assign_accumulate* call, in imgan_rag_accumulate's layout (K >= 1; rows n..K-1 zero):
+ * rag_segmentation.py:38-48 on the image SLIC ran on (run_slic :21-25 does run on image_lab), so
+ * the RAG step of that image needs no second pass over its pixels.  Same validity as the counts. */
+int imgan_slic_label_sums(int B, int H, int W, int S, int n, const void* workspace, int K,
+                          uint64_t* sums, imgan_stream_t stream);
+
 /* SLICSuperPixel.run(), slic.py:78-127: init + (num_iter-1) x (bin, assign, finalise). */
 int imgan_slic_run(const uint8_t* lab, int B, int H, int W, int S, int nx, int ny,
                    double colour_weight, int num_iter, int32_t* centres, int32_t* labels,
@@ -130,8 +137,9 @@ int imgan_slic_run(const uint8_t* lab, int B, int H, int W, int S, int nx, int n
  * edges: per image an open-addressed hash set of uint64 keys
  * ((min+1)<<32 | (max+1)), 0 = empty, capacity `edge_cap` (power of two);
  * must be zero-filled by the caller (as must sums).  overflow: int32 [B], zero-filled by
- * the caller, set to 1 if an image's edge set did not fit.  edges may be NULL (sums only).
- * Labels >= K are ignored for sums. */
+ * the caller, set to 1 if an image's edge set did not fit.  edges may be NULL (sums only);
+ * img and sums may both be NULL (adjacency only: the image is not read -- for callers that have
+ * the sums already, imgan_slic_label_sums).  Labels >= K are ignored for sums. */
 int imgan_rag_accumulate(const uint8_t* img, const int32_t* labels, int B, int H, int W, int K,
                          uint64_t* sums, uint64_t* edges, int64_t edge_cap, int32_t* overflow,
                          imgan_stream_t stream);

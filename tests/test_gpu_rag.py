@@ -248,3 +248,33 @@ def test_rag_pipeline_small_step_more_labels_than_requested():
     assert pipe.slic.n == 144 and pipe.K == 144
     merged, luts = pipe.step(torch.from_numpy(img[None]).cuda())
     assert int(merged.max()) >= 1 and pipe.redone == 0
+
+
+def test_slic_sums_and_adjacency_only_pass_equal_the_full_pass():
+    """The per-label sums the last SLIC round leaves (imgan_slic_label_sums) are the sums of
+    imgan_rag_accumulate over the same image and labels (rag_segmentation.py:38-48 on the image of
+    run_slic :21-25), and the pass without image and sums fills the same edge set."""
+    torch = _torch()
+    from imgan import ops
+    from oracle.color import bgr2lab_u8
+    B, H, W, K = 2, 180, 244, 70
+    lab = torch.from_numpy(np.stack([bgr2lab_u8(voronoi_image(H, W, 25, seed=s, noise=6.0))
+                                     for s in (3, 4)])).cuda()
+    plan = ops.SlicPlan(B, H, W, K)
+    labels, _ = plan.run(lab, 15, 10)
+    Kt = max(K, plan.n) + 5                                   # rows beyond n must come back zero
+    want_sums, want_edges = ops.rag_accumulate(lab, labels, Kt)
+    got = torch.full((B, Kt, 4), -1, dtype=torch.int64, device="cuda")
+    plan.label_sums(got)
+    assert torch.equal(got, want_sums)
+    assert int(got[:, plan.n:].abs().sum()) == 0
+    rp_full, rp_adj = ops.RagPlan(B, Kt), ops.RagPlan(B, Kt)
+    lut_full, st_full = rp_full.run(lab, labels, 0.65)
+    lut_adj, st_adj = rp_adj.run(lab, labels, 0.65, slic=plan)
+    assert torch.equal(rp_full.sums, rp_adj.sums)
+    assert torch.equal(torch.sort(rp_full.table, dim=1).values, torch.sort(rp_adj.table, dim=1).values)
+    assert torch.equal(lut_full, lut_adj) and int(st_full.abs().sum()) == 0 == int(st_adj.abs().sum())
+    for b in range(B):
+        keys = rp_adj.table[b][rp_adj.table[b] != 0].cpu().numpy().astype(np.uint64)
+        pairs = sorted((int(k >> np.uint64(32)) - 1, int(k & np.uint64(0xffffffff)) - 1) for k in keys)
+        assert pairs == [tuple(e) for e in want_edges[b].tolist()]
