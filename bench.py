@@ -258,9 +258,10 @@ def run_config_rag(steps, warmup):
                              traffic=pmc_traffic("3840x2160_K2000", "median_bits_kernel", npix),
                              note="bit-sliced selection, instruction bound by design"),
                roofline_line("bgr2lab_kernel", ms["bgr2lab"], 6, npix, profile=prof),
-               roofline_line("rag_accumulate_kernel + rag_merge_kernel", ms["rag_accumulate+merge"], 7,
+               roofline_line("rag_accumulate_kernel<false> (adjacency; sums from the last SLIC round) "
+                             "+ rag_merge_kernel", ms["rag_accumulate+merge"], 7,
                              npix, profile=prof, bound="atomics/latency"),
-               roofline_line("relabel_kernel", ms["relabel"], 8, npix, profile=prof)],
+               roofline_line("relabel4_kernel", ms["relabel"], 8, npix, profile=prof)],
            "path": {"bytes_per_px": path_bytes,
                     "achieved": round(path_bytes * npix * steps / dt / 1e9, 1), "unit": "GB/s",
                     "frac": round(path_bytes * npix * steps / dt / 1e9 / HBM_PEAK_GBS, 4),

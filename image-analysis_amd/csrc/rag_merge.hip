@@ -11,8 +11,9 @@
 //      rank after sorting) the forest is unique, so it is the one Kruskal's scan finds (:132-145)
 //   5. sum and sum of squares of the forest's weights, then the cut (:163-170) for every edge at
 //      once: keep iff w < mean(others) + c * std(others), in double-double arithmetic
-//   6. the second Kruskal pass (:173) replayed in rank order by one lane: a set keeps the list
-//      slot of the first endpoint's set (:124-130), which is what numbers the merged regions
+//   6. the second Kruskal pass (:173) replayed in rank order: a set keeps the list slot of the
+//      first endpoint's set (:124-130), which is what numbers the merged regions.  The order only
+//      matters inside one final region, so the regions are replayed side by side, one wave each
 //   7. ids = 1-based rank of a set's slot (:175-182), written as the relabel table
 #include "common.h"
 #include "../../include/imgan.h"
@@ -100,17 +101,27 @@ __global__ __launch_bounds__(MG_THREADS) void rag_merge_kernel(
     __syncthreads();
 
     // ---- 2. edge keys
-    for (long long i = tid; i < cap; i += MG_THREADS) {
-        const unsigned long long key = tab[i];
-        if (key == 0ull) continue;
-        const uint32_t u = (uint32_t)(key >> 32) - 1u, v = (uint32_t)key - 1u;
-        if (u >= v || v >= (uint32_t)K) {
-            sh[2] = 1;                                     // not an edge of labels 0..K-1
-            continue;
+    constexpr int KU = 8;                                  // table words in flight per thread
+    for (long long i0 = 0; i0 < cap; i0 += (long long)MG_THREADS * KU) {
+        unsigned long long got[KU];
+#pragma unroll
+        for (int q = 0; q < KU; ++q) {
+            const long long i = i0 + (long long)q * MG_THREADS + tid;
+            got[q] = i < cap ? tab[i] : 0ull;
         }
-        const int pos = atomicAdd(&sh[0], 1);
-        if (pos < MG_MAXE)
-            keys[pos] = ((unsigned long long)w2_of(meanpk[u], meanpk[v]) << 24) | ((unsigned long long)u << 12) | v;
+#pragma unroll
+        for (int q = 0; q < KU; ++q) {
+            const unsigned long long key = got[q];
+            if (key == 0ull) continue;
+            const uint32_t u = (uint32_t)(key >> 32) - 1u, v = (uint32_t)key - 1u;
+            if (u >= v || v >= (uint32_t)K) {
+                sh[2] = 1;                                 // not an edge of labels 0..K-1
+                continue;
+            }
+            const int pos = atomicAdd(&sh[0], 1);
+            if (pos < MG_MAXE)
+                keys[pos] = ((unsigned long long)w2_of(meanpk[u], meanpk[v]) << 24) | ((unsigned long long)u << 12) | v;
+        }
     }
     __syncthreads();
     const int E = sh[0];
@@ -275,30 +286,64 @@ __global__ __launch_bounds__(MG_THREADS) void rag_merge_kernel(
     }
     __syncthreads();
     // union by size keeps the finds short; comp[] becomes the list slot a set sits in; the sizes
-    // go where the edge words were (kept[] holds the ones still needed)
+    // go where the edge words were (kept[] holds the ones still needed).
+    // The replay is a chain of dependent LDS accesses per edge (0.28 us each, three quarters of
+    // this kernel when one lane walked the whole list), but only the order of the edges inside
+    // one final region matters: the regions -- the trees of the kept forest, found first by
+    // lock-free hooking -- are dealt to the 16 waves, and every wave replays its regions' edges
+    // in rank order on its own.
     uint32_t* size = edge;
-    for (int v = tid; v < K; v += MG_THREADS) comp[v] = parent[v] = (uint32_t)v, size[v] = 1u;
+    uint32_t* p2 = edge + MG_MAXK;                         // parent pointers of the kept forest
+    for (int v = tid; v < K; v += MG_THREADS) comp[v] = parent[v] = p2[v] = (uint32_t)v, size[v] = 1u;
     __syncthreads();
-    if (tid == 0) {
-        for (int i = 0; i < nkept; ++i) {
-            uint32_t u = kept[i] >> 16, v = kept[i] & 0xffffu;
-            while (parent[u] != u) {
-                parent[u] = parent[parent[u]];
-                u = parent[u];
-            }
-            while (parent[v] != v) {
-                parent[v] = parent[parent[v]];
-                v = parent[v];
-            }
-            if (u == v) continue;                          // cannot happen in a forest
-            const uint32_t slot = comp[u];                 // the first endpoint's set keeps its slot
-            if (size[u] < size[v]) {
-                parent[u] = v;
-                size[v] += size[u];
-                comp[v] = slot;
-            } else {
-                parent[v] = u;
-                size[u] += size[v];
+    for (int i = tid; i < nkept; i += MG_THREADS) {
+        uint32_t u = kept[i] >> 16, v = kept[i] & 0xffffu;
+        while (true) {
+            while (p2[u] != u) u = p2[u];
+            while (p2[v] != v) v = p2[v];
+            if (u == v) break;
+            const uint32_t hi = max(u, v), lo = min(u, v);
+            const uint32_t was = atomicMin(&p2[hi], lo);   // pointers only ever go down: no cycles
+            if (was == hi) break;                          // hi was a root and hangs under lo now
+            u = was, v = lo;                               // someone moved hi first: join that side too
+        }
+    }
+    __syncthreads();
+    for (int v = tid; v < K; v += MG_THREADS) {
+        uint32_t r = (uint32_t)v;
+        while (p2[r] != r) r = p2[r];
+        p2[v] = r;                                         // a reader meets the old parent or the root
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int base = 0; base < nkept; base += 64) {
+            const int i = base + lane;
+            const uint32_t word = i < nkept ? kept[i] : 0u;
+            const bool mine = i < nkept && (int)(p2[word >> 16] & (MG_THREADS / 64 - 1)) == wave;
+            unsigned long long todo = __ballot(mine);
+            while (todo) {                                 // every lane runs the same replay: uniform
+                const int l = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)word, l);
+                uint32_t u = w >> 16, v = w & 0xffffu;
+                while (parent[u] != u) u = parent[u];
+                while (parent[v] != v) v = parent[v];
+                if (u == v) continue;                      // cannot happen in a forest
+                const uint32_t slot = comp[u];             // the first endpoint's set keeps its slot
+                const uint32_t su = size[u], sv = size[v];
+                __builtin_amdgcn_wave_barrier();           // all reads of this edge before its writes
+                if (lane == 0) {
+                    if (su < sv) {
+                        parent[u] = v;
+                        size[v] = su + sv;
+                        comp[v] = slot;
+                    } else {
+                        parent[v] = u;
+                        size[u] = su + sv;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
