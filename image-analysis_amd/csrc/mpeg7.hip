@@ -503,8 +503,8 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     int H, int W, int nseg, int nbins, HmmdTab T, unsigned long long* __restrict__ cld_sums,
     int32_t* __restrict__ ehd_out, int32_t* __restrict__ csd_out, int32_t* __restrict__ too_big) {
     // pool: first the grey levels of the box's cells (edge histogram), then, for the colour
-    // structure, bitmaps over the cells: per colour of a pass its cells (R) and their dilation
-    // along x (D).  member / fits: the region's cells, and the cells where an 8 x 8 window fits.
+    // structure, bitmaps over the cells: per colour of a pass its cells, then, in place, their
+    // dilation along x.  member / fits: the region's cells, and the cells where an 8 x 8 window fits.
     __shared__ unsigned long long pool[RD_POOL];
     __shared__ uint8_t col[RD_CAP];
     __shared__ unsigned long long member[RD_WORDS], fits[RD_WORDS];
@@ -672,14 +672,13 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
         }
         int nslots = 1;
         for (int w = 0; w < 8; ++w) nslots += __popc(present[w]);
-        const int G = min(nslots, RD_POOL / (2 * nwords));     // >= 6
+        const int G = min(nslots, RD_POOL / nwords);           // >= 12
         const float inv_nw = 1.0f / (float)nwords;
         __syncthreads();                                      // the edge histogram is done with `gray`
         RD_MARK(2)
         for (int g0 = 0; g0 < nslots; g0 += G) {
             const int ng = min(G, nslots - g0);
             unsigned long long* Rb = pool;
-            unsigned long long* Db = pool + (size_t)G * nwords;
             for (int k = tid; k < ng * nwords; k += RD_THREADS) Rb[k] = 0ull;
             for (int k = tid; k < ng; k += RD_THREADS) cnts[k] = 0;
             __syncthreads();
@@ -725,20 +724,37 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
             }
             __syncthreads();
             RD_MARK(4)
-            for (int k = tid; k < ng * nwords; k += RD_THREADS) {
-                const int r = quot_inv(k, nwords, inv_nw), w = k - r * nwords;
-                const unsigned long long* Rr = Rb + (size_t)r * nwords;
-                const unsigned long long p = Rr[w], n = w + 1 < nwords ? Rr[w + 1] : 0ull;
-                unsigned long long d = p;
+            // dilation along x in place (a thread holds its words while the block reads): the pool
+            // then takes twice the slots per pass
+            {
+                constexpr int DW = (RD_POOL + RD_THREADS - 1) / RD_THREADS;
+                unsigned long long dil[DW];
 #pragma unroll
-                for (int dx = 1; dx < 8; ++dx) d |= (p >> dx) | (n << (64 - dx));
-                Db[k] = d;
+                for (int q = 0; q < DW; ++q) {
+                    const int k = tid + q * RD_THREADS;
+                    dil[q] = 0ull;
+                    if (k < ng * nwords) {
+                        const int r = quot_inv(k, nwords, inv_nw), w = k - r * nwords;
+                        const unsigned long long* Rr = Rb + (size_t)r * nwords;
+                        const unsigned long long p = Rr[w], n = w + 1 < nwords ? Rr[w + 1] : 0ull;
+                        unsigned long long d = p;
+#pragma unroll
+                        for (int dx = 1; dx < 8; ++dx) d |= (p >> dx) | (n << (64 - dx));
+                        dil[q] = d;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < DW; ++q) {
+                    const int k = tid + q * RD_THREADS;
+                    if (k < ng * nwords) Rb[k] = dil[q];
+                }
             }
             __syncthreads();
             RD_MARK(5)
             for (int k = tid; k < ng * nwords; k += RD_THREADS) {
                 const int r = quot_inv(k, nwords, inv_nw), w = k - r * nwords;
-                const unsigned long long* Dr = Db + (size_t)r * nwords;
+                const unsigned long long* Dr = Rb + (size_t)r * nwords;
                 unsigned long long v = Dr[w];
 #pragma unroll
                 for (int dy = 1; dy < 8; ++dy) v |= bits_at(Dr, w, dy * bw, nwords);
