@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
     uint32_t* tr = acc + maxc * 192;                            // [wave][row][column] transposition
     // bounding boxes of the new labels (P.bbox, last round only): the columns of a slot are the
     // lanes whose count is not zero; its rows come from a lane-private min / max pair
-    uint32_t* ybox = tr + 4 * 4 * 64;                           // [slot][min, max][lane]
+    uint32_t* ybox = tr + 4 * 4 * 64;                           // [slot][min, max][group of 4 lanes]
     int* const bbox = P.bbox;                                   // wave uniform
 
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2),
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
     for (int i = tid; i < maxc * 3 * 16; i += 256)
         reinterpret_cast<uint4*>(acc)[i] = make_uint4(0, 0, 0, 0);
     if (bbox)
-        for (int i = tid; i < maxc * 128; i += 256) ybox[i] = (i & 64) ? 0u : 0x7fffffffu;
+        for (int i = tid; i < maxc * 32; i += 256) ybox[i] = (i & 16) ? 0u : 0x7fffffffu;
 
     const int xr = lane;                                 // tile relative column of this lane
     const int x = x0 + xr;
@@ -837,11 +837,14 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                     atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)(wy0 + j) << 16));
                 }
                 if (bbox) {
+                    // one min / max pair per run of equal slots down the lane's rows (one run, as
+                    // a rule); four lanes share a copy, which keeps the rows' extremes small enough
+                    // in LDS for the seventh workgroup of a CU
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
-                        uint32_t* q = ybox + (__mul24(slot[j], 128) + lane);
-                        atomicMin(q, (uint32_t)(wy0 + j));
-                        atomicMax(q + 64, (uint32_t)(wy0 + j));
+                        uint32_t* q = ybox + (__mul24(slot[j], 32) + (lane >> 2));
+                        if (j == 0 || slot[j] != slot[j - 1]) atomicMin(q, (uint32_t)(wy0 + j));
+                        if (j == R - 1 || slot[j] != slot[j + 1]) atomicMax(q + 16, (uint32_t)(wy0 + j));
                     }
                 }
             }
@@ -865,9 +868,9 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                     atomicAdd(a + 64, ((p >> 16) & 0xffu) | 0x10000u);
                     atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)yr << 16));
                     if (bbox) {
-                        uint32_t* q = ybox + (__mul24(slot[j], 128) + lane);
+                        uint32_t* q = ybox + (__mul24(slot[j], 32) + (lane >> 2));
                         atomicMin(q, (uint32_t)yr);
-                        atomicMax(q + 64, (uint32_t)yr);
+                        atomicMax(q + 16, (uint32_t)yr);
                     }
                 } else {
                     // not covered this round: keeps its label (-1 in the first round, which
@@ -934,8 +937,8 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                     if ((acc[(s * 3 + 1) * 64 + col] >> 16) != 0u) {
                         xa = min(xa, col);
                         xb = max(xb, col);
-                        ya = min(ya, (int)ybox[s * 128 + col]);
-                        yb = max(yb, (int)ybox[s * 128 + 64 + col]);
+                        ya = min(ya, (int)ybox[s * 32 + t16]);       // the rows of this lane's four columns
+                        yb = max(yb, (int)ybox[s * 32 + 16 + t16]);
                     }
                 }
             }
@@ -1156,7 +1159,7 @@ static int assign_accumulate(const uint8_t* lab, int32_t* labels, int B, int H, 
     }
     if (bbox_out) {
         P.bbox = bbox_out;
-        lds_bytes += (size_t)P.maxc * 2 * 64 * sizeof(uint32_t);
+        lds_bytes += (size_t)P.maxc * 2 * 16 * sizeof(uint32_t);
         hipLaunchKernelGGL(slic_bbox_init_kernel, dim3((unsigned)imgan::cdiv(B * n, 256)), dim3(256),
                            0, st, bbox_out, B * n);
     }
