@@ -1309,7 +1309,9 @@ __device__ __forceinline__ bool segment_body(
     // Of the four backward links W / NW / N / NE only one more can be needed: with N present
     // the others follow from the neighbours' own links (NW-N, N-NE, W-N), and W covers NW;
     // what is left is NE next to a missing N, which is united explicitly below.  Those cells go
-    // on a list (one LDS atomic per wave and step) that the whole block then works through evenly:
+    // on a list (one LDS atomic per such cell; reserving a wave's entries with one atomic behind a
+    // ballot gave wrong component sizes in the dedup instantiations only, with __shfl and with
+    // v_readlane alike -- cause not found, left alone) that the whole block then works through evenly:
     // taken where they stand, a wave would run one union after the other for as many steps as any
     // of its lanes has such a cell, nearly all fourteen.  (Bit 25: no room on the list.)
 #pragma unroll
