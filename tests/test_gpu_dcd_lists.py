@@ -277,3 +277,24 @@ def test_checkerboard_overflows_the_join_list():
         assert np.array_equal(b[0][0, s].view(np.uint32), w_cen.view(np.uint32)), s
         assert np.array_equal(b[2][0, s].astype(np.uint64), w_stats), s
         assert sorted(int(v) for v in w_stats[:, 7]) == [len(idx) // 2, (len(idx) + 1) // 2], s
+
+
+def test_step_outputs_do_not_depend_on_the_run():
+    """The pixel lists come out in the order the sort pass's atomics land and the coherence pass
+    unites cells lock-free: the results must not depend on either.  Three passes of the bench step
+    over the same four 1080p images, every output compared bit for bit."""
+    torch = _torch()
+    from bench import synth_batch
+    from imgan.pipeline import FullPipeline
+    bgr = synth_batch(4, 1080, 1920, 400, 77, "cuda")
+    pipe = FullPipeline(4, 1080, 1920, 400)
+    ref = None
+    for _ in range(3):
+        rows, feats = pipe.step(bgr)
+        got = (rows.clone(), feats.clone().view(torch.int32), pipe.dcd.assign.clone())
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b)
