@@ -166,11 +166,7 @@ __global__ __launch_bounds__(256) void rag_accumulate_kernel(
         pc = above.c;
         sides(above, pcl, pcr);
     }
-    // one row ahead: the loads of row y + 1 are in flight while row y is worked on
-    RowIn next = fetch(ystart, SUMS);
-    for (int y = ystart; y < yend; ++y) {
-    const RowIn here = next;
-    if (y + 1 < yend) next = fetch(y + 1, SUMS);
+    auto process = [&](const RowIn& here) {
     const int l = here.c;
     const uint32_t raw = here.raw;
     int cl = -1, cr = -1;
@@ -206,6 +202,25 @@ __global__ __launch_bounds__(256) void rag_accumulate_kernel(
         }
         pc = l, pcl = cl, pcr = cr;
     }
+    };
+    // four rows per step, one step ahead: the loads of rows y + 4 .. y + 7 are in flight while rows
+    // y .. y + 3 are worked on (one row ahead left a block waiting for memory sixteen times)
+    constexpr int RC = 4;
+    static_assert(RAG_ROWS % RC == 0, "rows per block in whole steps");
+    RowIn ahead[RC];
+#pragma unroll
+    for (int u = 0; u < RC; ++u) ahead[u] = fetch(min(ystart + u, yend - 1), SUMS);
+    for (int y = ystart; y < yend; y += RC) {
+        RowIn now[RC];
+#pragma unroll
+        for (int u = 0; u < RC; ++u) now[u] = ahead[u];
+        if (y + RC < yend) {
+#pragma unroll
+            for (int u = 0; u < RC; ++u) ahead[u] = fetch(min(y + RC + u, yend - 1), SUMS);
+        }
+#pragma unroll
+        for (int u = 0; u < RC; ++u)
+            if (y + u < yend) process(now[u]);
     }
     if (SUMS) flush(true);
     if (E) {
