@@ -9,6 +9,7 @@ cp $S/bench.json profiles/r02_bench.json
 cp $S/kt/b_kernel_stats.csv profiles/r02_bench_kernel_stats.csv
 cp $S/pmc_B64.txt profiles/r02_pmc_B64.txt
 cp $S/pmc_rag4k_B4.txt profiles/r02_pmc_rag4k_B4.txt
+cp $S/pmc_mosaic4096.txt profiles/r02_pmc_mosaic4096.txt
 python tools/kstats.py $S/kt 3 > profiles/r02_bench_kernel_summary.txt
 python tools/kstats.py $S/kt_rag 4 > profiles/r02_rag4k_kernel_summary.txt
 python tools/kstats.py $S/kt_mosaic 4 > profiles/r02_mosaic_kernel_summary.txt

@@ -11,4 +11,5 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 cd $R
 bash tools/pmc_passes.sh all 64 rf2/pmc fetch write sq1 lds > gpurun_out/rf2/pmc_B64.txt 2>&1
 bash tools/pmc_passes.sh rag4k 4 rf2/pmcrag fetch write sq1 lds > gpurun_out/rf2/pmc_rag4k_B4.txt 2>&1
+bash tools/pmc_passes.sh mosaic 1 rf2/pmcmos fetch write sq1 lds > gpurun_out/rf2/pmc_mosaic4096.txt 2>&1
 tail -n 5 gpurun_out/rf2/pmc_B64.txt; tail -n 5 gpurun_out/rf2/pmc_rag4k_B4.txt
