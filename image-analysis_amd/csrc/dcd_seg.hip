@@ -472,7 +472,9 @@ __device__ __forceinline__ void unite16(uint16_t* par, uint32_t a, uint32_t b) {
 // coincide or a cluster is crowded out).  Kept out of line on purpose: inlined into the fold, the
 // 16-cluster kernels built by ROCm 7.2 never leave the pixel loop below (the same loop as a
 // callee, and with a constant bound inlined, run fine; the ISA reads correct -- cause not found),
-// and the call costs 1 % of the stage.
+// and the call costs 1 % of the stage.  (The tier kernels spill several hundred scalar registers,
+// and builds that raise the pressure a little more have come out wrong with this call present and
+// right without it: see "Known fragility" in DESIGN.md before touching the register budget.)
 // Writes the drawn pixel's colour to cen[j], cen[stride + j], cen[2 * stride + j].
 __device__ __noinline__ void resample_empty(unsigned long long empty, const uint32_t* pix,
                                             const uint16_t* pos, int n, int bw, int xmin, int ymin,
