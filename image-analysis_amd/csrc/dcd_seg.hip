@@ -474,7 +474,8 @@ __device__ __forceinline__ void unite16(uint16_t* par, uint32_t a, uint32_t b) {
 // callee, and with a constant bound inlined, run fine; the ISA reads correct -- cause not found),
 // and the call costs 1 % of the stage.  (The tier kernels spill several hundred scalar registers,
 // and builds that raise the pressure a little more have come out wrong with this call present and
-// right without it: see "Known fragility" in DESIGN.md before touching the register budget.)
+// right without it -- until the wave index was declared uniform: see "Known fragility" in DESIGN.md
+// before touching the register budget.)
 // Writes the drawn pixel's colour to cen[j], cen[stride + j], cen[2 * stride + j].
 __device__ __noinline__ void resample_empty(unsigned long long empty, const uint32_t* pix,
                                             const uint16_t* pos, int n, int bw, int xmin, int ymin,
@@ -608,7 +609,11 @@ __device__ __forceinline__ bool segment_body(
     // the listed mode calls this in a loop: without the fence the compiler computes everything that
     // depends on the thread index alone once, ahead of the loop, and keeps it all in registers
     if (LISTED) asm volatile("" : "+v"(tid_));
-    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
+    // wave: known to the compiler as wave uniform, so that `if (wave == 0)` is a scalar branch.  The
+    // fence above hides that from it; with the serial section of a round behind a *divergent*
+    // branch, builds under a little more register pressure than this one came out wrong (DESIGN.md,
+    // "Known fragility")
+    const int tid = tid_, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef IMGAN_SEG_TIMING
     unsigned long long t_last_ = wall_clock64();
 #endif
