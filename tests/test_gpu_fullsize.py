@@ -229,3 +229,38 @@ def test_mosaic_16k_superpixel_descriptors():
     want_sums, want_edges = _torch_rag(torch, lab[0], labels[0], K)
     assert torch.equal(sums[0], want_sums)
     assert np.array_equal(edges[0].astype(np.int64), want_edges.cpu().numpy())
+
+    # per-superpixel colour layout / edge histogram / colour structure at this size
+    # (region_desc_kernel as bench.py's configs[4] step runs it): properties for all 49,729 rows,
+    # and a sample of regions exactly against the oracle on a crop that holds the region
+    from oracle import mpeg7_std as M
+    rd = ops.RegionDescriptorPlan(B, H, W, n)
+    cld, ehd, csd = rd.run(bgr, labels)
+    torch.cuda.synchronize()
+    assert int(rd.too_big.item()) == 0
+    box = ops.label_bbox(labels, n)[0]
+    empty = seg_px == 0
+    assert not bool(cld[0][empty].any()) and not bool(ehd[0][empty].any()) and not bool(csd[0][empty].any())
+    bw = (box[:, 2] - box[:, 0] + 1).clamp(min=0).long()
+    bh = (box[:, 3] - box[:, 1] + 1).clamp(min=0).long()
+    nwin = csd[0, :, 256].long()
+    # boxes below 256 x 256: sub-sampling 1, so at most (bw - 7)(bh - 7) windows; a window with a
+    # cell of the region counts once and holds at least one colour; a colour at most nwin times
+    assert bool((nwin <= (bw - 7).clamp(min=0) * (bh - 7).clamp(min=0)).all())
+    hist = csd[0, :, :256].long()
+    assert bool((hist.max(dim=1).values <= nwin).all()) and bool((hist.sum(dim=1) >= nwin).all())
+    # edge blocks: the five edge types of a sub-image never exceed its full blocks
+    assert bool((ehd[0, :, :80].view(n, 16, 5).sum(dim=2) <= ehd[0, :, 80:]).all())
+    assert int(ehd[0, :, 80:].sum()) > n and int(nwin.sum()) > n
+    rng = np.random.RandomState(5)
+    for r in rng.choice(n, 48, replace=False).tolist() + [0, n - 1, 222, 223]:
+        x0, y0, x1, y1 = [int(v) for v in box[r].tolist()]
+        if x1 < x0:
+            continue
+        ci = bgr[0, y0:y1 + 1, x0:x1 + 1].cpu().numpy()
+        cl = labels[0, y0:y1 + 1, x0:x1 + 1].cpu().numpy()
+        assert np.array_equal(cld[0, r].cpu().numpy(), M.region_colour_layout_full(ci, cl, r)), r
+        counts, nblk = M.region_edge_histogram_counts(ci, cl, r)
+        assert np.array_equal(ehd[0, r].cpu().numpy(), np.concatenate([counts, nblk])), r
+        h_, nw_ = M.region_colour_structure_counts(ci, cl, r)
+        assert np.array_equal(csd[0, r].cpu().numpy(), np.concatenate([h_, [nw_]])), r

@@ -161,6 +161,19 @@ def test_4k_k2000_slic_rag_against_oracles():
     assert np.array_equal(merged.astype(np.float64), merged_want)
     assert merged.max() > 1
 
+    # the path bench.py times for configs[2]: RagPipeline.step = median + Lab + SLIC + the
+    # adjacency-only pass + the per-label sums of the last SLIC round + the merge on the device
+    # (rag_merge_kernel: LDS sort of the edge keys, Boruvka forest, leave-one-out cut, replay),
+    # at this geometry (n = 1947 labels, about 5.8 k edges) against the same oracle result
+    from imgan.pipeline import RagPipeline
+    pipe = RagPipeline(1, H, W, K)
+    assert pipe.rag is not None, "K = 2000 must take the device merge"
+    got, luts_dev = pipe.step(dev.unsqueeze(0))
+    assert int(pipe.rag.status.cpu().numpy().max()) == 0 and pipe.redone == 0
+    assert np.array_equal(pipe.slic.labels[0].cpu().numpy(), labels[0].cpu().numpy())
+    assert np.array_equal(got[0].cpu().numpy().astype(np.float64), merged_want)
+    assert np.array_equal(luts_dev[0].cpu().numpy()[:K], luts[0][:K])
+
 
 def test_bear_geometry_1050x1573_k200():
     """configs[0] as written: the reference's own CPU case runs SLIC on bear.jpg at full size
@@ -186,3 +199,100 @@ def test_colour_structure_subsampling_16():
     counts, nblk = M.edge_histogram_counts(img)                 # 122-pixel blocks
     ehd = dp.edge_histogram(torch.from_numpy(img).cuda().unsqueeze(0))[0].cpu().numpy()
     assert np.array_equal(ehd[:80], counts) and np.array_equal(ehd[80:], nblk)
+
+
+def test_1080p_full_pipeline_hash_init_against_c_oracle():
+    """configs[1] as bench.py runs it: FullPipeline.step with the device-side hash rule for the
+    initial centres (imgan_dcd_init_hash) and the pixel lists; every superpixel's centres,
+    statistics and round count against the C oracle given the restated hash picks."""
+    torch = _torch()
+    from imgan.pipeline import FullPipeline
+    from oracle import c_oracle
+    from oracle.color import bgr2lab_u8
+    from oracle.dcd_ref import mix32
+    H, W, K, k, seed = 1080, 1920, 400, 8, 12345
+    img = voronoi_image(H, W, K, seed=1081)
+    pipe = FullPipeline(1, H, W, K, dominant=k, dcd_seed=seed)
+    rows, feats = pipe.step(torch.from_numpy(img).cuda().unsqueeze(0))
+    assert pipe.dcd.lists and int(pipe.dcd.n_big.item()) == 0
+    lab_np = bgr2lab_u8(img)
+    want_labels, _ = c_oracle.slic_run(lab_np, K, 15, 10)
+    labels = pipe.slic.labels[0].cpu().numpy()
+    assert np.array_equal(labels, want_labels)
+    n = pipe.n
+    flat = labels.ravel()
+    labf = lab_np.reshape(-1, 3)
+    order = np.argsort(flat, kind="stable")
+    bounds = np.searchsorted(flat[order], np.arange(n + 1))
+    # the device rule, restated: slot j of a segment takes the pixel with the smallest
+    # (h, p), h = mix32(p * 0x9e3779b1 + seed), among those with h % k == j; an empty slot takes
+    # the smallest key of the segment
+    p_all = np.arange(H * W, dtype=np.uint64)
+    h_all = mix32((p_all * np.uint64(0x9e3779b1) + np.uint64(seed)) & np.uint64(0xffffffff))
+    stats = pipe.dcd.stats[0].cpu().numpy()
+    cen = pipe.centres[0].cpu().numpy()
+    rounds = pipe.dcd.rounds()[0].cpu().numpy()[0]
+    f = feats.view(1, n, k, 8)[0].cpu().numpy()
+    for s in range(n):
+        idx = order[bounds[s]:bounds[s + 1]]
+        assert len(idx) >= k
+        hs = h_all[idx]
+        keys = (hs << np.uint64(32)) | idx.astype(np.uint64)
+        init = []
+        for j in range(k):
+            cand = np.nonzero(hs % np.uint64(k) == j)[0]
+            pick = cand[np.argmin(keys[cand])] if len(cand) else int(np.argmin(keys))
+            init.append(int(pick))
+        rc = np.stack(np.divmod(idx, W), axis=1).astype(np.int32)
+        # the injected form takes sorted distinct indices or not: the oracle takes them as given
+        w_assign, w_cen, w_stats, w_rounds = c_oracle.dcd_segment(
+            labf[idx], rc, np.array(init, np.int32), max_rounds=200,
+            resample_idx=resample_rule(idx, seed, k))
+        assert rounds[s] == w_rounds, (s, rounds[s], w_rounds)
+        assert np.array_equal(cen[s].view(np.uint32), w_cen.view(np.uint32)), s
+        assert np.array_equal(stats[s].astype(np.uint64), w_stats), s
+        assert np.array_equal(pipe.dcd.assign[0].view(-1)[torch.from_numpy(idx).cuda()].cpu().numpy(),
+                              w_assign.astype(np.uint8)), s
+        st = w_stats.astype(np.float64)
+        live = st[:, 0] > 0
+        assert np.allclose(f[s, live, 6], st[live, 0] / len(idx), rtol=1e-6)
+        assert np.allclose(f[s, live, 7], st[live, 7] / st[live, 0], rtol=1e-6)
+
+
+def test_region_descriptors_at_mosaic_geometry():
+    """configs[4]'s per-superpixel CLD / EHD / CSD at the mosaic's step: a 1168 x 1168 image with
+    K = 256 has S = 73 like the 16384^2 / K = 50,000 mosaic (boxes up to 146^2 cells, 4-pixel edge
+    blocks, all colours of a region pooled in one pass of region_desc_kernel), through
+    FullPipeline(per_region=True) as bench.py runs it; every region against oracle.mpeg7_std."""
+    torch = _torch()
+    from imgan.pipeline import FullPipeline
+    from oracle import mpeg7_std as M
+    H = W = 1168
+    K = 256
+    img = voronoi_image(H, W, K // 2, seed=1168, noise=8.0)
+    pipe = FullPipeline(1, H, W, K, dominant=8, per_region=True)
+    assert pipe.slic.S == 73 and pipe.n == 15 * 15
+    rows, _ = pipe.step(torch.from_numpy(img).cuda().unsqueeze(0))
+    assert int(pipe.region_desc.too_big.item()) == 0
+    labels = pipe.slic.labels[0].cpu().numpy()
+    cld = pipe.region_desc.cld[0].cpu().numpy()
+    ehd = pipe.region_desc.ehd[0].cpu().numpy()
+    csd = pipe.region_desc.csd[0].cpu().numpy()
+    assert rows.shape == (1, pipe.n * (12 + 96 + 257))
+    checked = 0
+    for r in range(pipe.n):
+        ys, xs = np.nonzero(labels == r)
+        if len(ys) == 0:
+            assert not cld[r].any() and not ehd[r].any() and not csd[r].any()
+            continue
+        # the oracle on a crop that holds the whole region (its forms are relative to the box)
+        y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+        ci, cl = img[y0:y1, x0:x1], labels[y0:y1, x0:x1]
+        assert np.array_equal(cld[r], M.region_colour_layout_full(ci, cl, r)), r
+        counts, nblk = M.region_edge_histogram_counts(ci, cl, r)
+        assert np.array_equal(ehd[r], np.concatenate([counts, nblk])), r
+        hist, nwin = M.region_colour_structure_counts(ci, cl, r)
+        assert np.array_equal(csd[r], np.concatenate([hist, [nwin]])), r
+        checked += 1
+    assert checked >= pipe.n - 2
+    assert ehd[:, 80:].sum() > 0 and csd[:, 256].sum() > 0
