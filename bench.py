@@ -286,6 +286,7 @@ def run_config_mosaic(steps, warmup):
         pipe.step(bgr, timed=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    segments_left = pipe.finish()
     ms = pipe.stage_times_ms()
     npix = B * H * W
     t_bar = pipe.mean_lloyd_rounds()
@@ -298,6 +299,7 @@ def run_config_mosaic(steps, warmup):
            "value": round(npix * steps / dt / 1e6, 2), "unit": "megapixels/sec",
            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "dcd_segments_at_round_cap": pipe.segments_at_round_cap(),
+           "dcd_segments_left_to_streaming_rounds": int(segments_left),
            "roofline": roofline_line("dcd_segment_kernel x3 tiers (+seg_scatter_kernel, seg_plan_kernel)",
                                      ms["dcd_segments"], dcd_bytes, npix, profile=prof, bound="valu/lds",
                                      note="timed around the C call (imgan_dcd_segments_listed); SURVEY 8d "
@@ -432,6 +434,7 @@ def main():
     bgr = synth_batch(B, H, W, K, 1234 + rank * B, "cuda")
     from imgan.pipeline import FullPipeline
     from imgan.shard import gather_descriptors_async
+    from imgan._lib import LIB_PATH
     pipe = FullPipeline(B, H, W, K, colour_weight=cw, num_iter=num_iter, dominant=8)
 
     def barrier():
@@ -455,6 +458,31 @@ def main():
     index = (pending[0].result(), pending[1].result()) if pending is not None else None
     barrier()
     dt = time.perf_counter() - t0
+    # what the collective costs on its own (after the timed region: the timed steps overlap it with
+    # the next step's kernels): the two all-gathers of one step, issued and joined back to back
+    rccl = None
+    if dist.is_initialized():
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        reps = 5
+        ev[0].record()
+        for _ in range(reps):
+            a = gather_descriptors_async(image_rows, n_total=B * world)
+            b = gather_descriptors_async(region_rows, n_total=B * world)
+            a.result(), b.result()
+        ev[1].record()
+        torch.cuda.synchronize()
+        row_bytes = image_rows[0].numel() * image_rows.element_size() + \
+            region_rows[0].numel() * region_rows.element_size()
+        rccl = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                "collectives_per_step": 2,
+                "allgather_bytes_per_step": int(row_bytes * B * world),
+                "allgather_bytes_per_rank_contributed": int(row_bytes * B),
+                "allgather_ms": round(ev[0].elapsed_time(ev[1]) / reps, 4),
+                "index_rows": [int(index[0].shape[0]), int(index[1].shape[0])],
+                "note": "descriptor rows of every rank -> replicated index; in the timed steps the "
+                        "collective runs on the backend's stream under the next step's kernels, "
+                        "allgather_ms is its cost alone (issued and joined back to back)"}
+    segments_left = pipe.finish()                  # superpixels beyond the on-chip pass (deferred check)
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -497,7 +525,8 @@ def main():
                                    (B, W, H, K, pipe.n, pipe.slic.S, num_iter, cw,
                                     "Lab + SLIC + CLD + EHD + CSD(256) + DCD(k=8 per superpixel, "
                                     "%.1f Lloyd rounds per pixel on chip)" % t_bar),
-                       "global_batch": B * world, "parallelism": "batch-sharded x%d" % world},
+                       "global_batch": B * world, "parallelism": "batch-sharded x%d" % world,
+                       "library": os.path.relpath(LIB_PATH, ROOT)},
             # the dominant kernel by time: one C call (imgan_dcd_segments_listed) = the pass that sorts
             # the pixels by segment + the three capacity tiers of dcd_segment_kernel, one launch each
             "roofline": roofline_line(
@@ -512,6 +541,7 @@ def main():
                      "the kernel is VALU / LDS bound" % t_bar),
             "roofline_kernels": others,
             "dcd_segments_at_round_cap": pipe.segments_at_round_cap(),
+            "dcd_segments_left_to_streaming_rounds": int(segments_left),
             "path": {"bytes_per_px": round(path_bytes_px, 1),
                      "achieved": round(path_bytes_px * npix * args.steps / dt / 1e9 * 1.0, 1),
                      "unit": "GB/s", "frac": round(path_bytes_px * npix * args.steps / dt / 1e9
@@ -519,6 +549,8 @@ def main():
                      "note": "whole step against SURVEY 8d's algorithmic bytes "
                              "(6 Lab + 63 SLIC + %g CLD/EHD/CSD + DCD)" % desc_bytes},
         }
+        if rccl is not None:
+            out["rccl"] = rccl
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["cpu_baseline_numpy"] = cpu_baseline(H, W, K, cw)
         if world == 1 and not args.no_configs:

@@ -870,13 +870,8 @@ static __device__ __align__(256) unsigned long long scratch[(size_t)CLD_STATIC_M
 constexpr int CLD_MAX_DEVICES = 64;
 static std::atomic<unsigned long long*> g_cld_static_ptr[CLD_MAX_DEVICES];
 
-extern "C" int imgan_cld_static(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out,
-                                imgan_stream_t stream) {
-    if (int rc = cld_check(bgr, B, H, W, cld_out)) return rc;
-    if (B > CLD_STATIC_MAX_B)
-        return imgan::fail(imgan::E_RANGE, "imgan_cld_static: at most " +
-                                               std::to_string(CLD_STATIC_MAX_B) +
-                                               " images per call (static scratch); use imgan_cld");
+// The device address of the array on the current device: resolved once per device, kept.
+static int cld_static_address(unsigned long long** out, int* dev_out) {
     int dev = -1;
     IMGAN_HIP(hipGetDevice(&dev));
     IMGAN_REQUIRE(dev >= 0 && dev < CLD_MAX_DEVICES, "imgan_cld_static: device ordinal out of range");
@@ -887,6 +882,39 @@ extern "C" int imgan_cld_static(const uint8_t* bgr, int B, int H, int W, int32_t
         IMGAN_REQUIRE(p != nullptr, "imgan_cld_static: no device address for the static scratch");
         ptr = (unsigned long long*)p;
         g_cld_static_ptr[dev].store(ptr, std::memory_order_release);   // same value from every thread
+    }
+    *out = ptr;
+    if (dev_out) *dev_out = dev;
+    return 0;
+}
+
+// Set-up of imgan_cld_static for the current device, for callers that will call it where the
+// look-up of the array's address is not allowed (hipGetSymbolAddress may load the code object: not
+// a stream operation, not capturable): call this once per device beforehand.
+extern "C" int imgan_cld_static_prepare(void) {
+    unsigned long long* ptr = nullptr;
+    return cld_static_address(&ptr, nullptr);
+}
+
+extern "C" int imgan_cld_static(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out,
+                                imgan_stream_t stream) {
+    if (int rc = cld_check(bgr, B, H, W, cld_out)) return rc;
+    if (B > CLD_STATIC_MAX_B)
+        return imgan::fail(imgan::E_RANGE, "imgan_cld_static: at most " +
+                                               std::to_string(CLD_STATIC_MAX_B) +
+                                               " images per call (static scratch); use imgan_cld");
+    unsigned long long* ptr = nullptr;
+    int dev = -1;
+    if (int rc = cld_static_address(&ptr, &dev)) return rc;
+    // the array is the current device's copy: a stream of another device would run the kernels
+    // there with this device's address
+    if (stream) {
+        hipDevice_t sdev = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess)
+            IMGAN_REQUIRE((int)sdev == dev, "imgan_cld_static: the stream belongs to another device "
+                                            "than the current one (hipSetDevice first)");
+        else
+            (void)hipGetLastError();                         // a query some contexts refuse: not fatal
     }
     return cld_run(bgr, B, H, W, cld_out, ptr, (hipStream_t)stream, "imgan_cld_static");
 }

@@ -13,6 +13,7 @@
 #include "../../include/imgan.h"
 #include <algorithm>
 #include <math.h>
+#include "cut_rule.h"
 #include <atomic>
 #include <numeric>
 #include <string>
@@ -445,19 +446,15 @@ extern "C" int imgan_rag_merge_host(const int32_t* means, const double* weights,
     std::vector<Edge> kept;
     const size_t m = mst.size();
     if (m >= 2) {
-        long double T = 0.0L, Q = 0.0L;
+        // both sums over the rounded float64 weights, in double-double (cut_rule.h: the rule the
+        // device merge applies too)
+        imgan_cut::DD T{0.0, 0.0}, Q{0.0, 0.0};
         for (const Edge& e : mst) {
-            T += (long double)e.w;
-            Q += means ? (long double)e.w2 : (long double)e.w * (long double)e.w;
+            T = imgan_cut::dd_add(T, imgan_cut::DD{e.w, 0.0});
+            Q = imgan_cut::dd_add(Q, imgan_cut::dd_square(e.w));
         }
-        for (const Edge& e : mst) {
-            long double w = (long double)e.w;
-            long double q = means ? (long double)e.w2 : w * w;
-            long double mean = (T - w) / (long double)(m - 1);
-            long double var = (Q - q) / (long double)(m - 1) - mean * mean;
-            if (var < 0.0L) var = 0.0L;
-            if (e.w < (double)(mean + (long double)c_factor * sqrtl(var))) kept.push_back(e);
-        }
+        for (const Edge& e : mst)
+            if (imgan_cut::keep_edge(e.w, T, Q, (int)m, c_factor)) kept.push_back(e);
     }   // m == 1: mean of an empty list is NaN -> the edge is dropped (:166-168)
 
     // :173 second Kruskal from singletons, :175-182 ids in surviving-list order

@@ -18,25 +18,15 @@
 #include "common.h"
 #include "../../include/imgan.h"
 #include <math.h>
+#include "cut_rule.h"
 
 namespace {
 
 constexpr int MG_THREADS = 1024, MG_MAXK = 4096, MG_MAXE = 16384;
 constexpr uint32_t MG_NONE = 0xffffffffu;
 
-struct DD {
-    double hi, lo;
-};
-__device__ __forceinline__ DD two_sum(double a, double b) {
-    const double s = a + b, bb = s - a;
-    return DD{s, (a - (s - bb)) + (b - bb)};
-}
-__device__ __forceinline__ DD dd_add(DD x, DD y) {
-    DD s = two_sum(x.hi, y.hi);
-    const double e = s.lo + (x.lo + y.lo);
-    const double hi = s.hi + e;
-    return DD{hi, e - (hi - s.hi)};
-}
+using imgan_cut::DD;
+using imgan_cut::dd_add;
 
 __device__ __forceinline__ int w2_of(uint32_t mu, uint32_t mv) {
     const int d0 = (int)(mu & 255u) - (int)(mv & 255u);
@@ -215,14 +205,14 @@ __global__ __launch_bounds__(MG_THREADS) void rag_merge_kernel(
     }
 
     // ---- 5. forest statistics and the cut
-    DD t_loc{0.0, 0.0};
-    long long q_loc = 0;
+    DD t_loc{0.0, 0.0}, q_loc{0.0, 0.0};
     int m_loc = 0;
     for (int e = tid; e < E; e += MG_THREADS)
         if (state[e] == 1) {
             const int w2 = w2_of(meanpk[edge[e] >> 16], meanpk[edge[e] & 0xffffu]);
-            t_loc = dd_add(t_loc, DD{sqrt((double)w2), 0.0});
-            q_loc += w2;
+            const double w = sqrt((double)w2);
+            t_loc = dd_add(t_loc, DD{w, 0.0});
+            q_loc = dd_add(q_loc, imgan_cut::dd_square(w));    // of the rounded weight (cut_rule.h)
             ++m_loc;
         }
     // tree reduction over the workgroup: [hi | lo | q | m] x 1024 would not fit; fold through waves
@@ -230,42 +220,28 @@ __global__ __launch_bounds__(MG_THREADS) void rag_merge_kernel(
     for (int off = 32; off >= 1; off >>= 1) {
         DD o{__shfl_xor(t_loc.hi, off), __shfl_xor(t_loc.lo, off)};
         t_loc = dd_add(t_loc, o);
-        q_loc += __shfl_xor(q_loc, off);
+        DD oq{__shfl_xor(q_loc.hi, off), __shfl_xor(q_loc.lo, off)};
+        q_loc = dd_add(q_loc, oq);
         m_loc += __shfl_xor(m_loc, off);
     }
     if ((tid & 63) == 0) {
         const int w = tid >> 6;
-        shd[4 * w] = t_loc.hi, shd[4 * w + 1] = t_loc.lo;
-        shd[4 * w + 2] = (double)q_loc;                    // < 2^53: exact
-        shd[4 * w + 3] = (double)m_loc;
+        shd[5 * w] = t_loc.hi, shd[5 * w + 1] = t_loc.lo;
+        shd[5 * w + 2] = q_loc.hi, shd[5 * w + 3] = q_loc.lo;
+        shd[5 * w + 4] = (double)m_loc;
     }
     __syncthreads();
-    DD T{0.0, 0.0};
-    double Q = 0.0;
+    DD T{0.0, 0.0}, Q{0.0, 0.0};
     int m = 0;
     for (int w = 0; w < MG_THREADS / 64; ++w) {
-        T = dd_add(T, DD{shd[4 * w], shd[4 * w + 1]});
-        Q += shd[4 * w + 2];
-        m += (int)shd[4 * w + 3];
+        T = dd_add(T, DD{shd[5 * w], shd[5 * w + 1]});
+        Q = dd_add(Q, DD{shd[5 * w + 2], shd[5 * w + 3]});
+        m += (int)shd[5 * w + 4];
     }
     for (int e = tid; e < E; e += MG_THREADS) {
         if (state[e] != 1) continue;
-        bool keep = false;
-        if (m >= 2) {                                      // m == 1: mean of nothing is NaN, dropped
-            const int w2 = w2_of(meanpk[edge[e] >> 16], meanpk[edge[e] & 0xffffu]);
-            const double w = sqrt((double)w2), n1 = (double)(m - 1);
-            const DD s = dd_add(T, DD{-w, 0.0});           // sum of the others
-            const double mean_hi = s.hi / n1;
-            const double mean_lo = (fma(-mean_hi, n1, s.hi) + s.lo) / n1;
-            const double sq_hi = mean_hi * mean_hi;
-            const double sq_lo = fma(mean_hi, mean_hi, -sq_hi) + 2.0 * mean_hi * mean_lo;
-            const double qq = Q - (double)w2;              // exact
-            const double a_hi = qq / n1;
-            const double a_lo = fma(-a_hi, n1, qq) / n1;
-            double var = (a_hi - sq_hi) + (a_lo - sq_lo);
-            if (!(var > 0.0)) var = 0.0;
-            keep = w < mean_hi + (mean_lo + c_factor * sqrt(var));
-        }
+        const int w2 = w2_of(meanpk[edge[e] >> 16], meanpk[edge[e] & 0xffffu]);
+        const bool keep = imgan_cut::keep_edge(sqrt((double)w2), T, Q, m, c_factor);
         state[e] = keep ? 3 : 2;
     }
     __syncthreads();
@@ -378,7 +354,7 @@ __global__ __launch_bounds__(MG_THREADS) void rag_merge_kernel(
     if (tid == 0) status[b] = 0;
 }
 
-constexpr size_t MG_LDS = (size_t)MG_MAXE * 8 + (size_t)MG_MAXK * 4 + 32 * 4 + 16 * 4 * 8;
+constexpr size_t MG_LDS = (size_t)MG_MAXE * 8 + (size_t)MG_MAXK * 4 + 32 * 4 + 16 * 5 * 8;
 
 }  // namespace
 

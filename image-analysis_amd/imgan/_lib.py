@@ -7,8 +7,16 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# IMGAN_LIB: an experiment build of the same library (tools/exp_run.sh); never a fallback
-LIB_PATH = os.environ.get("IMGAN_LIB") or os.path.join(_HERE, "libimgan_hip.so")
+import sys
+
+# IMGAN_LIB: an experiment build of the same library (tools/exp_run.sh); never a fallback.  It
+# replaces the product library for every importer, so it is announced on stderr, and bench.py
+# records the path it ran with (config.library).
+PRODUCT_LIB = os.path.join(_HERE, "libimgan_hip.so")
+LIB_PATH = os.environ.get("IMGAN_LIB") or PRODUCT_LIB
+if LIB_PATH != PRODUCT_LIB:
+    sys.stderr.write("imgan: IMGAN_LIB is set -- running the experiment build %s, not the product "
+                     "library\n" % LIB_PATH)
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -88,6 +96,7 @@ SIGNATURES = {
     "imgan_cld": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_cld_scratch_bytes": (c_size_t, [c_int]),
     "imgan_cld_static": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "imgan_cld_static_prepare": (c_int, []),
     "imgan_ehd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_ehd_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "imgan_csd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

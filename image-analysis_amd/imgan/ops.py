@@ -504,10 +504,14 @@ class DcdPlan(object):
         seed the same value serves both.
         counted: self.counts already holds the pixel count of every segment
         (SlicPlan.label_counts(out=self.counts)); counted otherwise (plans with lists only).
-        max_segment_px: an upper bound on the pixels of any segment that the caller can prove (a
-        SLIC superpixel lies inside its centre's 2S x 2S window, slic.py:94-100); when it is within
-        the on-chip capacity no segment can be left for the streaming rounds, so the count of
-        such segments is not read back and the call does not synchronise."""
+        max_segment_px: the size the caller expects no segment to exceed (a SLIC superpixel
+        normally lies inside its centre's 2S x 2S window, slic.py:94-100).  When it is within the
+        on-chip capacity the count of segments left for the streaming rounds is not read back
+        here, so the call does not synchronise.  That is an expectation, not a proof -- a pixel
+        that no window reaches keeps a stale label (slic.py:81-116), which can stretch a label's
+        box or count past the capacity -- so the counter stays on the device and the caller
+        settles it later: unhandled_segments() reads it, finish_large() runs the streaming rounds
+        for what was left (FullPipeline.finish(), bench.py after its timed loop)."""
         lab = as_batch(_dev(lab, torch.uint8, "lab"))
         if labels.dim() == 2:
             labels = labels.unsqueeze(0)
@@ -541,10 +545,39 @@ class DcdPlan(object):
                 check(fn(_ptr(lab), _ptr(labels), *shape, 1 if use_hash else 0, cseed,
                          _ptr(centres), _ptr(self.assign), _ptr(self.state), _ptr(self.stats),
                          _ptr(self.bbox), _ptr(self.n_big), int(max_rounds), _stream()))
+            self._pending = (use_hash, cseed, state_for_skip)
             if max_segment_px is not None and int(max_segment_px) <= self.LDS_CAPACITY:
-                self.big_segments = 0
-            else:
-                self.big_segments = int(self.n_big.item())
+                self.big_segments = 0               # deferred: see unhandled_segments()
+                self.rounds_run = 0
+                return centres, self.assign
+            self.big_segments = int(self.n_big.item())
+        self._pending = None
+        return self._streaming_rounds(lab, labels, centres, use_hash, cseed, state_for_skip,
+                                      max_rounds, check_every, streaming_only)
+
+    def unhandled_segments(self):
+        """Segments the last on-chip pass left for the streaming rounds (one synchronisation)."""
+        return int(self.n_big.item())
+
+    def finish_large(self, lab, labels, centres, max_rounds=1000, check_every=1):
+        """Settles a kmeans() call that skipped the read-back of the counter: runs the streaming
+        rounds for the segments the on-chip pass could not hold.  Returns their number."""
+        if getattr(self, "_pending", None) is None:
+            return 0
+        use_hash, cseed, state_for_skip = self._pending
+        self._pending = None
+        self.big_segments = self.unhandled_segments()
+        if self.big_segments:
+            lab = as_batch(_dev(lab, torch.uint8, "lab"))
+            if labels.dim() == 2:
+                labels = labels.unsqueeze(0)
+            self._streaming_rounds(lab, labels, centres, use_hash, cseed, state_for_skip,
+                                   max_rounds, check_every, False)
+        return self.big_segments
+
+    def _streaming_rounds(self, lab, labels, centres, use_hash, cseed, state_for_skip, max_rounds,
+                          check_every, streaming_only):
+        shape = (self.B, self.H, self.W, self.nseg, self.k)
         self.rounds_run = 0
         if self.big_segments == 0:
             return centres, self.assign

@@ -74,7 +74,9 @@ class FullPipeline(object):
         p = ops._ptr
 
         def go():
-            # a superpixel lies inside its centre's window: at most (2S)^2 pixels
+            # a superpixel normally lies inside its centre's window, at most (2S)^2 pixels: the
+            # count of segments beyond the on-chip capacity is not read here (no synchronisation
+            # in a step); finish() settles it
             self._timed("dcd_segments", timed, lambda: self.dcd.kmeans(
                 self.lab, labels, self.centres, seed=self.seed, max_rounds=self.max_rounds,
                 check_every=self.check_every, boxed=getattr(self, "boxed", False),
@@ -104,6 +106,20 @@ class FullPipeline(object):
         feats = self.run_dcd(timed)
         image_rows = torch.cat([cld[:, 0, :6], cld[:, 1, :3], cld[:, 2, :3], ehd, csd], dim=1)
         return image_rows, feats.view(self.B, -1)
+
+    def finish(self):
+        """Settles the last step (one synchronisation): superpixels that did not fit the on-chip
+        dominant-colour pass (a stale label stretched their box or count, see DcdPlan.kmeans) go
+        through the streaming rounds, and their statistics and features are redone.  Returns the
+        number of such superpixels (0 on every batch measured so far); the features returned
+        by step() are final when it is 0."""
+        left = self.dcd.finish_large(self.lab, self.slic.labels, self.centres,
+                                     max_rounds=self.max_rounds, check_every=self.check_every)
+        if left:
+            stats = self.dcd.statistics(self.lab, self.slic.labels)
+            check(lib.imgan_dcd_features(ops._ptr(stats), ops._ptr(self.centres), self.B, self.n,
+                                         self.k, ops._ptr(self.features), ops._stream()))
+        return left
 
     def stage_times_ms(self):
         """Mean device time per C call of every stage recorded with timed=True."""

@@ -318,9 +318,16 @@ size_t imgan_cld_scratch_bytes(int B);
  * static device array of the library instead (2 KiB per image, 2 MiB per GPU, held until the
  * process ends), so B <= 1024 (IMGAN_E_RANGE beyond).  Calls no hipMalloc / hipFree or any other
  * allocating routine.  Every call on a GPU shares that GPU's array (cleared at the start of
- * each call): calls that overlap on one GPU -- two streams, two threads -- race. */
+ * each call): calls that overlap on one GPU -- two streams, two threads -- race.
+ * The array used is the CURRENT device's (hipSetDevice), which must be the device `stream`
+ * belongs to (IMGAN_E_INVALID otherwise).  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress, which may load the code object: not a stream operation), so under graph
+ * capture call imgan_cld_static_prepare() -- the same look-up and nothing else, for the current
+ * device -- once per device before the capture begins; it has no counterpart in the reference
+ * either. */
 int imgan_cld_static(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out,
                      imgan_stream_t stream);
+int imgan_cld_static_prepare(void);
 int imgan_ehd(const uint8_t* bgr, int B, int H, int W, int32_t* ehd_out, void* scratch,
               imgan_stream_t stream);
 size_t imgan_ehd_scratch_bytes(int B, int H, int W);

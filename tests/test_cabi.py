@@ -169,3 +169,43 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not bad.search(src), "product file uses the oracle: " + fn
+
+
+def test_leave_one_out_cut_with_equal_weights_follows_numpy():
+    """rag_segmentation.py:163-170 on forests whose other weights are all equal: numpy's std is
+    exactly 0 there (one other weight, or a uniform forest of a size whose sum is exact), so the
+    strict '<' drops an edge that weighs the same as the others.  The merge must agree with the
+    literal numpy rule (oracle/rag_ref.py), not keep the edge on rounding noise."""
+    from imgan import ops
+    from oracle.rag_ref import RAGOracle
+
+    def literal(means, edges, c):
+        ora = RAGOracle.__new__(RAGOracle)
+        K = len(means)
+        ng = {v: set() for v in range(K)}
+        for u, v in edges:
+            ng[u].add(float(v))
+            ng[v].add(float(u))
+        col = {v: np.array(means[v]) for v in range(K)}
+        clusters = np.arange(K, dtype=np.float64).reshape(1, K)
+        out = ora.concat_similar_regs(ora.find_edges(ng, col), clusters, c_factor=c)[0]
+        return out.ravel().astype(np.int64)
+
+    cases = [
+        # two forest edges of the same weight sqrt(14): each sees one other of its own weight
+        ([[0, 0, 0], [1, 2, 3], [2, 4, 6]], [[0, 1], [1, 2]]),
+        # a uniform path of five vertices (four equal weights, each sees three equal others)
+        ([[10 * i, 0, 3 * i] for i in range(5)], [[i, i + 1] for i in range(4)]),
+        # uniform weights with a heavier one: the heavy edge goes, the others stay
+        ([[0, 0, 0], [3, 0, 0], [6, 0, 0], [9, 0, 0], [9, 40, 0]], [[0, 1], [1, 2], [2, 3], [3, 4]]),
+        # one other weight, smaller / larger
+        ([[0, 0, 0], [5, 0, 0], [5, 7, 0]], [[0, 1], [1, 2]]),
+    ]
+    for means, edges in cases:
+        for c in (0.0, 0.65, 2.0):
+            m = np.array(means, np.int32)
+            e = np.array(edges, np.int32)
+            got = ops.rag_merge_host(len(means), e, c, means=m)["lut"]
+            want = literal(means, edges, c)
+            # same partition, canonical numbering on both sides for these path graphs
+            assert np.array_equal(got, want), (means, edges, c, got, want)

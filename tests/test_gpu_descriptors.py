@@ -370,3 +370,55 @@ def test_region_descriptors_odd_shapes_and_limits():
         assert np.array_equal(ehd[r], we), r
         assert np.array_equal(csd[r], ws), r
     assert csd[0, 256] > 0 and csd[1, 256] == 0 and ehd[3, 80:].sum() > 0
+
+
+def test_large_cluster_centre_sums_integer_vs_float32():
+    """A region whose clusters hold more than 65,793 pixels (a merged region of the class API on
+    a large image): mpeg7Descriptors.py:96-99 adds the points up in float32, which rounds beyond
+    2^24; the product adds integers (deviation table).  The product must
+    equal the C restatement (integer sums) bit for bit, and stay within north_star's 1e-4 of the
+    literal numpy rule (np.sum(dtype=float32), oracle/dcd_ref.py)."""
+    torch = _torch()
+    from imgan import ops
+    from imgan._lib import lib, check
+    from oracle import c_oracle
+    from oracle.color import bgr2lab_u8
+    from oracle.dcd_ref import dominant_colour
+    H = W = 400
+    k = 2
+    rng = np.random.RandomState(9)
+    img = np.zeros((H, W, 3), dtype=np.float64)
+    img[:, :220] = (200, 210, 220)                               # two bright, well separated colours
+    img[:, 220:] = (60, 240, 150)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    lab_np = bgr2lab_u8(img)
+    labels = np.zeros((H, W), dtype=np.int32)
+    idx = np.arange(H * W)
+    init = np.array([5 * W + 7, 300 * W + 390], dtype=np.int32)
+    cen0 = lab_np.reshape(-1, 3)[init].astype(np.float32).reshape(1, 1, k, 3)
+    plan = ops.DcdPlan(1, H, W, 1, k)
+    lab = torch.from_numpy(lab_np).cuda().unsqueeze(0)
+    dl = torch.from_numpy(labels).cuda().unsqueeze(0)
+    cen = torch.from_numpy(cen0.copy()).cuda()
+    plan.kmeans(lab, dl, cen, max_rounds=1000)
+    assert plan.big_segments == 1                                # streaming rounds (beyond LDS)
+    stats = plan.statistics(lab, dl).cpu().numpy()[0, 0]
+    rounds = int(plan.rounds()[0].cpu().numpy()[0, 0])
+    rc = np.stack(np.divmod(idx, W), axis=1).astype(np.int32)
+    w_assign, w_cen, w_stats, w_rounds = c_oracle.dcd_segment(lab_np.reshape(-1, 3), rc, init)
+    assert (w_stats[:, 0] > 65793).all() and (w_stats[:, 1:4].max(axis=0) > (1 << 24)).any()
+    assert rounds == w_rounds
+    assert np.array_equal(cen.cpu().numpy()[0, 0].view(np.uint32), w_cen.view(np.uint32))
+    assert np.array_equal(stats.astype(np.uint64), w_stats)
+    assert np.array_equal(plan.assign[0].cpu().numpy().ravel(), w_assign.astype(np.uint8))
+    feats = torch.empty((1, 1, k, 8), dtype=torch.float32, device="cuda")
+    check(lib.imgan_dcd_features(ops._ptr(plan.stats), ops._ptr(cen), 1, 1, k, ops._ptr(feats),
+                                 ops._stream()))
+    f = feats.cpu().numpy()[0, 0]
+    lit, lit_rounds = dominant_colour(lab_np.reshape(-1, 3), rc, list(init), (H, W))
+    assert lit_rounds == rounds
+    for j in range(k):
+        mean, var, share, coh = lit[j]
+        assert np.allclose(f[j, 0:3], mean, rtol=1e-4, atol=0), (j, f[j, 0:3], mean)
+        assert np.allclose(f[j, 3:6], var, rtol=1e-4, atol=1e-3)
+        assert np.isclose(f[j, 6], share, rtol=1e-6) and np.isclose(f[j, 7], coh, rtol=1e-6)

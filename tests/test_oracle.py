@@ -133,3 +133,28 @@ def test_mpeg7_std_sanity():
     assert c.sum() == 0
     cld = M.colour_layout(grey)
     assert cld.shape == (12,) and (cld[1:6] == 16).all()      # AC terms of a flat image quantise to 16
+
+
+def test_float32_centre_sums_part_from_integer_sums_beyond_2_24():
+    """mpeg7Descriptors.py:96-99 adds a cluster's points up in float32 (np.sum(..., dtype=float32)).
+    The product and the C restatement add them as integers, which is the same number while the
+    sum stays below 2^24 (a cluster of at most 65,793 pixels can never exceed it: 65,793 x 255 <
+    2^24) and a different one beyond that.  This pins where the two part and by how much (the
+    deviation row of DESIGN.md section 2); the gap depends on numpy's summation order, so the
+    bounds are loose."""
+    rng = np.random.RandomState(3)
+    exact_n = (1 << 24) // 255                                   # 65,793
+    worst = np.full((exact_n, 3), 255, dtype=np.float32)
+    assert np.array_equal(np.sum(worst, axis=0, dtype=np.float32), worst.astype(np.int64).sum(axis=0))
+    for n in (1000, 20000, exact_n):
+        pts = rng.randint(0, 256, (n, 3)).astype(np.float32)
+        assert np.array_equal(np.sum(pts, axis=0, dtype=np.float32), pts.astype(np.int64).sum(axis=0)), n
+    gaps = {}
+    for n in (300000, 2000000):
+        pts = rng.randint(128, 256, (n, 3)).astype(np.float32)   # bright cluster: sums well past 2^24
+        f32 = np.sum(pts, axis=0, dtype=np.float32).astype(np.float64)
+        exact = pts.astype(np.int64).sum(axis=0).astype(np.float64)
+        assert (exact > (1 << 24)).all()
+        gaps[n] = float(np.abs(f32 - exact).max() / exact.max())
+    # the float32 running sum is off, but by little: a relative gap that grows with the cluster
+    assert 0.0 < gaps[300000] < 2e-4 and gaps[300000] <= gaps[2000000] < 2e-3, gaps

@@ -39,3 +39,12 @@ def test_cld_static_rejects_oversize_batch():
     out = torch.zeros((1, 3, 64), dtype=torch.int32, device="cuda")
     rc = lib.imgan_cld_static(bgr.data_ptr(), 1025, 8, 8, out.data_ptr(), None)
     assert rc == -3 and "1024" in last_error()
+
+
+def test_cld_static_prepare_is_idempotent():
+    from imgan._lib import lib, check
+    check(lib.imgan_cld_static_prepare())
+    check(lib.imgan_cld_static_prepare())
+    bgr = torch.randint(0, 256, (1, 40, 56, 3), dtype=torch.uint8, device="cuda")
+    ref, out = _cld_pair(lib, check, bgr)
+    assert np.array_equal(ref, out)
