@@ -1,0 +1,130 @@
+// Shared by the LDS-resident dominant-colour kernels (dcd_seg.hip: box gather and plain pixel
+// lists; dcd_tiers.hip: the dedup tiers): the pixel lists, the capacity tiers and the 16-bit
+// union-find of the coherence pass.
+#pragma once
+#include "common.h"
+#include "dcd_common.h"
+
+namespace imgan_dcd {
+
+// median of three unsigned words in one instruction (the compiler has no builtin for it)
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;   // one global_load_dword at any address
+
+// Capacity tiers (pixels a workgroup holds in LDS at 6 B each, and its thread count).
+// 768 threads = 3 waves on each SIMD of the CU per workgroup, 6 with the second workgroup: measured
+// against 512 / 640 / 896 / 1024 threads (5.6 / 6.3 / 8.0 / 7.4 ms where this takes 5.1): the
+// Lloyd rounds are latency bound per workgroup, and wave counts that do not divide by four leave
+// one SIMD holding the others up at every barrier.
+constexpr int CAP_SMALL = 12288, THREADS_SMALL = 768;
+// listed mode only: three workgroups per CU for the segments that leave room for them; the two
+// smaller tiers sized so that the accumulators of the dedup kernels fit beside the pixels
+constexpr int CAP_TINY_D = 7168, THREADS_TINY = 512;       // 512 x 14
+constexpr int CAP_SMALL_D = 11520;                         // 768 x 15
+// (A fourth tier below these, 5,376 px / 384 threads = four workgroups per CU, was measured: 4.46
+// against 4.16 ms at K = 400 and 5.6 against 4.9 at K = 800 -- six waves do not spread over four
+// SIMDs, the same finding as for 640 and 896 threads.)
+constexpr int CAP_SMALL_K16 = 10752;   // 9 .. 16 colours: twice the accumulators, still two workgroups per CU
+constexpr int CAP_LARGE = 22528, THREADS_LARGE = 1024;     // >= 4 S^2 of the 1080p / K=400 grid
+
+constexpr uint32_t NO_COLOUR = 0xffffffffu;            // an empty slot of the colour table
+constexpr int DEDUP_PROBES = 64;                       // linear probes before a segment is given up (16 / 512 measured: +6 % / +11 %)
+
+// ---- pixel lists (imgan_dcd_segments_listed).  With the pixel count of every segment known up
+// front (the last SLIC round has it), one streaming pass sorts the pixels by segment: every
+// segment owns a contiguous run of {Lab, y << 16 | x} entries.  The segment kernel then loads its
+// run with straight reads instead of scanning its bounding box (about 2.5 cells per pixel for a
+// superpixel, with a ballot and an LDS atomic per 64 cells), and every segment goes directly to
+// the capacity tier that fits it.
+struct SegLists {
+    int* hdr;               // [64]: 0..3 length of the lists below, 8..11 their ticket counters
+    uint32_t* offsets;      // [nsegs] start of every segment's run (inside its image's H*W slab)
+    uint32_t* ends;         // [nsegs] end of the run: start + count, clamped to the slab
+    uint32_t* cursor;       // [nsegs] entries written so far
+    int* tier[4];           // [nsegs] each: segment ids by tier; [3]: what the dedup tiers hand to the plain body
+    uint32_t* spix;         // [B*H*W] Lab of the listed pixels
+    uint32_t* sxy;          // [B*H*W] y << 16 | x
+};
+
+inline size_t seg_lists_bytes(size_t nsegs, size_t npx) {
+    return 256 + 7 * imgan::align_up(nsegs * 4, 256) + 2 * imgan::align_up(npx * 4, 256);
+}
+
+inline SegLists bind_lists(void* scratch, size_t nsegs, size_t npx) {
+    char* p = (char*)scratch;
+    SegLists L;
+    L.hdr = (int*)p;
+    p += 256;
+    L.offsets = (uint32_t*)p;
+    p += imgan::align_up(nsegs * 4, 256);
+    L.ends = (uint32_t*)p;
+    p += imgan::align_up(nsegs * 4, 256);
+    L.cursor = (uint32_t*)p;
+    p += imgan::align_up(nsegs * 4, 256);
+    for (int t = 0; t < 4; ++t) {
+        L.tier[t] = (int*)p;
+        p += imgan::align_up(nsegs * 4, 256);
+    }
+    L.spix = (uint32_t*)p;
+    p += imgan::align_up(npx * 4, 256);
+    L.sxy = (uint32_t*)p;
+    return L;
+}
+
+// ---- union-find on 16-bit parents in LDS (the hardware has no 16-bit LDS atomics: a
+// compare-and-swap on the containing word stands in for atomicMin)
+// find with path halving.  The halving store may race with a concurrent atomic_min16 on the
+// same entry; either value is an ancestor of the cell, so no link is lost (the uniting thread
+// carries on with the value it displaced).
+__device__ __forceinline__ uint32_t find16(volatile uint16_t* par, uint32_t a) {
+    while (true) {
+        const uint32_t p = par[a];
+        if (p == a) return a;
+        const uint32_t g = par[p];
+        if (g == p) return p;
+        par[a] = (uint16_t)g;
+        a = g;
+    }
+}
+
+__device__ __forceinline__ uint32_t atomic_min16(uint16_t* par, uint32_t idx, uint32_t val) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(par) + (idx >> 1);
+    const uint32_t sh = (idx & 1u) * 16u;
+    uint32_t old = *reinterpret_cast<volatile uint32_t*>(w);
+    while (true) {
+        const uint32_t cur = (old >> sh) & 0xffffu;
+        if (cur <= val) return cur;
+        const uint32_t nw = (old & ~(0xffffu << sh)) | (val << sh);
+        const uint32_t prev = atomicCAS(w, old, nw);
+        if (prev == old) return cur;
+        old = prev;
+    }
+}
+
+__device__ __forceinline__ void unite16(uint16_t* par, uint32_t a, uint32_t b) {
+    while (true) {
+        a = find16(par, a);
+        b = find16(par, b);
+        if (a == b) return;
+        if (a < b) {
+            uint32_t t = a;
+            a = b;
+            b = t;
+        }
+        const uint32_t old = atomic_min16(par, a, b);      // hang the larger root under the smaller
+        if (old == a) return;
+        a = old;                                           // somebody re-parented a meanwhile
+    }
+}
+
+}  // namespace imgan_dcd
+
+// dcd_tiers.hip: the dedup tier launches of imgan_dcd_segments_listed
+int imgan_dcd_launch_dedup_tiers(const uint8_t* lab, int B, int H, int W, int nseg, int k, int use_hash,
+                                 uint32_t seed, float* centres, uint8_t* assign,
+                                 imgan_dcd::SegState* seg, unsigned long long* stats, const int* bbox,
+                                 int max_rounds, const imgan_dcd::SegLists& L, hipStream_t st);

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "../../include/imgan.h"
 #include "dcd_common.h"
+#include "dcd_lists.h"
 #include <stdlib.h>
 
 using namespace imgan_dcd;
@@ -46,28 +47,6 @@ __device__ unsigned long long seg_timing[16];
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// median of three unsigned words in one instruction (the compiler has no builtin for it)
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;   // one global_load_dword at any address
-
-// 768 threads = 3 waves on each SIMD of the CU per workgroup, 6 with the second workgroup: measured
-// against 512 / 640 / 896 / 1024 threads (5.6 / 6.3 / 8.0 / 7.4 ms where this takes 5.1): the
-// Lloyd rounds are latency bound per workgroup, and wave counts that do not divide by four leave
-// one SIMD holding the others up at every barrier.
-constexpr int CAP_SMALL = 12288, THREADS_SMALL = 768;       // 6 B of LDS per pixel
-// listed mode only: three workgroups per CU for the segments that leave room for them; the two
-// smaller tiers sized so that the 32-bit accumulators of the dedup kernels fit beside the pixels
-constexpr int CAP_TINY_D = 7168, THREADS_TINY = 512;       // 512 x 14
-constexpr int CAP_SMALL_D = 11520;                         // 768 x 15
-// (A fourth tier below these, 5,376 px / 384 threads = four workgroups per CU, was measured: 4.46
-// against 4.16 ms at K = 400 and 5.6 against 4.9 at K = 800 -- six waves do not spread over four
-// SIMDs, the same finding as for 640 and 896 threads.)
-constexpr int CAP_SMALL_K16 = 10752;   // 9 .. 16 colours: twice the accumulators, still two workgroups per CU
-constexpr int CAP_LARGE = 22528, THREADS_LARGE = 1024;     // >= 4 S^2 of the 1080p / K=400 grid
 // The small tier packs {count, sum0} and {sum1, sum2} into 16-bit halves of two words per
 // lane-private copy: a copy sees at most CAP / 64 pixels, and 192 * 255 < 65536.
 static_assert((CAP_SMALL / 64) * 255 < 65536, "packed accumulators would overflow");
@@ -170,47 +149,6 @@ __global__ void seg_bbox_init_kernel(int* __restrict__ bbox, int nsegs) {
     bb[1] = 0x7fffffff;
     bb[2] = -1;
     bb[3] = -1;
-}
-
-// ---- pixel lists (imgan_dcd_segments_listed).  With the pixel count of every segment known up
-// front (the last SLIC round has it), one streaming pass sorts the pixels by segment: every
-// segment owns a contiguous run of {Lab, y << 16 | x} entries.  The segment kernel then loads its
-// run with straight reads instead of scanning its bounding box (about 2.5 cells per pixel for a
-// superpixel, with a ballot and an LDS atomic per 64 cells), and every segment goes directly to
-// the capacity tier that fits it.
-struct SegLists {
-    int* hdr;               // [64]: 0..2 length of the lists below, 8..10 their ticket counters
-    uint32_t* offsets;      // [nsegs] start of every segment's run (inside its image's H*W slab)
-    uint32_t* ends;         // [nsegs] end of the run: start + count, clamped to the slab
-    uint32_t* cursor;       // [nsegs] entries written so far
-    int* tier[3];           // [nsegs] each: segment ids by tier
-    uint32_t* spix;         // [B*H*W] Lab of the listed pixels
-    uint32_t* sxy;          // [B*H*W] y << 16 | x
-};
-
-size_t seg_lists_bytes(size_t nsegs, size_t npx) {
-    return 256 + 6 * imgan::align_up(nsegs * 4, 256) + 2 * imgan::align_up(npx * 4, 256);
-}
-
-SegLists bind_lists(void* scratch, size_t nsegs, size_t npx) {
-    char* p = (char*)scratch;
-    SegLists L;
-    L.hdr = (int*)p;
-    p += 256;
-    L.offsets = (uint32_t*)p;
-    p += imgan::align_up(nsegs * 4, 256);
-    L.ends = (uint32_t*)p;
-    p += imgan::align_up(nsegs * 4, 256);
-    L.cursor = (uint32_t*)p;
-    p += imgan::align_up(nsegs * 4, 256);
-    for (int t = 0; t < 3; ++t) {
-        L.tier[t] = (int*)p;
-        p += imgan::align_up(nsegs * 4, 256);
-    }
-    L.spix = (uint32_t*)p;
-    p += imgan::align_up(npx * 4, 256);
-    L.sxy = (uint32_t*)p;
-    return L;
 }
 
 // Room a tier needs for a segment: its pixels, and the 2-byte cell grid of the coherence pass over
@@ -421,52 +359,6 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const uint8_t* __restr
     }
 }
 
-// ---- union-find on 16-bit parents in LDS (the hardware has no 16-bit LDS atomics: a
-// compare-and-swap on the containing word stands in for atomicMin)
-// find with path halving.  The halving store may race with a concurrent atomic_min16 on the
-// same entry; either value is an ancestor of the cell, so no link is lost (the uniting thread
-// carries on with the value it displaced).
-__device__ __forceinline__ uint32_t find16(volatile uint16_t* par, uint32_t a) {
-    while (true) {
-        const uint32_t p = par[a];
-        if (p == a) return a;
-        const uint32_t g = par[p];
-        if (g == p) return p;
-        par[a] = (uint16_t)g;
-        a = g;
-    }
-}
-
-__device__ __forceinline__ uint32_t atomic_min16(uint16_t* par, uint32_t idx, uint32_t val) {
-    uint32_t* w = reinterpret_cast<uint32_t*>(par) + (idx >> 1);
-    const uint32_t sh = (idx & 1u) * 16u;
-    uint32_t old = *reinterpret_cast<volatile uint32_t*>(w);
-    while (true) {
-        const uint32_t cur = (old >> sh) & 0xffffu;
-        if (cur <= val) return cur;
-        const uint32_t nw = (old & ~(0xffffu << sh)) | (val << sh);
-        const uint32_t prev = atomicCAS(w, old, nw);
-        if (prev == old) return cur;
-        old = prev;
-    }
-}
-
-__device__ __forceinline__ void unite16(uint16_t* par, uint32_t a, uint32_t b) {
-    while (true) {
-        a = find16(par, a);
-        b = find16(par, b);
-        if (a == b) return;
-        if (a < b) {
-            uint32_t t = a;
-            a = b;
-            b = t;
-        }
-        const uint32_t old = atomic_min16(par, a, b);      // hang the larger root under the smaller
-        if (old == a) return;
-        a = old;                                           // somebody re-parented a meanwhile
-    }
-}
-
 // mpeg7Descriptors.py:101 for the clusters in `empty` (a wave-uniform mask), by one whole wave while
 // the others wait at the round's barrier: rare (a cluster only runs empty when sampled colours
 // coincide or a cluster is crowded out).  Kept out of line on purpose: inlined into the fold, the
@@ -570,8 +462,6 @@ __device__ __noinline__ void resample_empty_listed(unsigned long long empty, con
 // handed back (false) and the workgroup runs the MODE_LISTED body on it.  (Sending segments below
 // 3072 or 4608 pixels straight to the plain body was measured: slower than the table for all.)
 constexpr int MODE_FIRST = 0, MODE_RETRY = 1, MODE_LISTED = 2, MODE_DEDUP = 3;
-constexpr uint32_t NO_COLOUR = 0xffffffffu;            // an empty slot of the colour table
-constexpr int DEDUP_PROBES = 64;                       // linear probes before a segment is given up (16 / 512 measured: +6 % / +11 %)
 
 template <int KM, int CAP, int THREADS, int MODE>
 __device__ __forceinline__ bool segment_body(
@@ -1237,7 +1127,7 @@ __device__ __forceinline__ bool segment_body(
             ++yy;
             xx -= bw;
         }
-        assign[img + (size_t)(uint32_t)(__mul24(ymin + yy, W) + xmin + xx)] = (uint8_t)bi;
+        if (assign) assign[img + (size_t)(uint32_t)(__mul24(ymin + yy, W) + xmin + xx)] = (uint8_t)bi;
     }
     __syncthreads();
     SEG_MARK(5)
@@ -1289,7 +1179,7 @@ __device__ __forceinline__ bool segment_body(
                 int xx = o - __mul24(yy, bw);
                 yy += (xx >= bw) - (xx < 0);
                 xx = o - __mul24(yy, bw);
-                assign[img + (size_t)(uint32_t)(__mul24(ymin + yy, W) + xmin + xx)] = (uint8_t)(keep[t] >> 16);
+                if (assign) assign[img + (size_t)(uint32_t)(__mul24(ymin + yy, W) + xmin + xx)] = (uint8_t)(keep[t] >> 16);
             }
     }
     uint16_t* par = reinterpret_cast<uint16_t*>(smem);
@@ -1594,8 +1484,8 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
                                          uint64_t* stats, const int32_t* bbox, const int32_t* counts,
                                          void* list_scratch, int32_t* n_big_out, int max_rounds,
                                          imgan_stream_t stream) {
-    IMGAN_REQUIRE(lab && labels && centres && assign && state && stats && bbox && counts &&
-                      list_scratch && n_big_out,
+    IMGAN_REQUIRE(lab && labels && centres && state && stats && bbox && counts && list_scratch &&
+                      n_big_out,
                   "imgan_dcd_segments_listed: null pointer");
     IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535 && H <= 65535 && W <= 65536,
                   "imgan_dcd_segments_listed: bad shape");
@@ -1612,7 +1502,7 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
     SegLists L = bind_lists(list_scratch, nsegs, npx);
     IMGAN_HIP(hipMemsetAsync(state, 0, D.total, st));
     IMGAN_HIP(hipMemsetAsync(n_big_out, 0, 4, st));
-    IMGAN_HIP(hipMemsetAsync(assign, 0xff, npx, st));
+    if (assign) IMGAN_HIP(hipMemsetAsync(assign, 0xff, npx, st));
     // IMGAN_DCD_DEDUP=0: the plain listed kernels on every tier (for comparisons)
     static const bool dedup = [] {
         const char* e = getenv("IMGAN_DCD_DEDUP");
@@ -1627,6 +1517,31 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
     hipLaunchKernelGGL(seg_scatter_kernel<false>, gsc, dim3(256), 0, st, lab, labels, B, H, W, nseg, L,
                        (int32_t*)nullptr);
     unsigned long long* stt = (unsigned long long*)stats;
+    // IMGAN_DCD_TIERS=old: the round-2 dedup kernels of this file (for comparisons)
+    static const bool new_tiers = [] {
+        const char* e = getenv("IMGAN_DCD_TIERS");
+        return !(e && e[0] == 'o');
+    }();
+    if (dedup && new_tiers) {
+        // the dedup tiers (dcd_tiers.hip), smallest first; what overflows every colour table ends
+        // up on list 3 and takes the plain body here, one workgroup per CU
+        if (int rc = imgan_dcd_launch_dedup_tiers(lab, B, H, W, nseg, k, use_hash_init, seed, centres,
+                                                  assign, seg, stt, bbox, max_rounds, L, st))
+            return rc;
+        dim3 grid((unsigned)std::min<size_t>(nsegs, 256));
+        if (k <= 8) {
+            if (int rc = launch_tier<8, CAP_LARGE, THREADS_LARGE, MODE_LISTED>(
+                    grid, st, lab, labels, B, H, W, nseg, k, use_hash_init, seed, centres, assign, seg, stt,
+                    bbox, nullptr, n_big_out, max_rounds, L, 3))
+                return rc;
+        } else {
+            if (int rc = launch_tier<16, CAP_LARGE, THREADS_LARGE, MODE_LISTED>(
+                    grid, st, lab, labels, B, H, W, nseg, k, use_hash_init, seed, centres, assign, seg, stt,
+                    bbox, nullptr, n_big_out, max_rounds, L, 3))
+                return rc;
+        }
+        return imgan::check_launch("imgan_dcd_segments_listed");
+    }
     // The large tier first (its few long jobs should not be what everything else waits for at the
     // end); a grid of a few workgroups per CU slot, which draw segments until the tier's list is
     // empty.  (Measured: the tiers on three streams side by side gain 2 % at 64 images and lose

@@ -1,0 +1,692 @@
+// Dominant colours, the tier kernels of imgan_dcd_segments_listed (mpeg7Descriptors.py:76-129):
+// one workgroup owns one segment, reads its run of the pixel lists once and runs the whole Lloyd
+// loop, the statistics and the coherence pass on chip.
+//
+// The rounds walk the DISTINCT COLOURS of the segment: the assignment of a pixel depends on its
+// colour alone and the sums are integers, so one entry per distinct colour, weighted by the number
+// of pixels that have it, gives the same centres, assignments and round counts at a fraction of
+// the distance evaluations (0.41 distinct colours per pixel on the bench batch).  The colours are
+// collected in an LDS hash table while the run is loaded, closed up into dense arrays
+// {colour | cluster << 24, count}, and every pixel keeps the index of its colour (2 B).
+//
+// What differs from the kernels in dcd_seg.hip (which stay as the box-gather front end and as the
+// plain body for segments whose colours do not fit a table):
+//   * ONE barrier per Lloyd round.  The accumulators are three buffers used in turn (round r adds
+//     into buffer r % 3; after the barrier of round r every wave clears its share of buffer
+//     (r - 1) % 3, which all waves finished reading before they reached that barrier, and which is
+//     next added to after the barrier of round r + 1).  After the barrier EVERY wave folds the
+//     buffer itself, moves the centres and applies the stop rule: the same instructions on the same
+//     numbers, so all waves hold the same centres and take the same decision without a second
+//     barrier, and no wave waits for one wave's serial section.  The centres never pass through
+//     LDS: lane j of every wave holds centre j, and the distance loop reads them as scalars.
+//   * no calls and no second body: an empty cluster is re-seeded by the whole block in line (the
+//     mask is the same in every wave, so the branch is uniform over the block), and a segment
+//     whose colours overflow the table is put on the next tier's list (larger table) -- the last
+//     tier hands it to the plain body of dcd_seg.hip, launched after the tiers.
+//   * the assignment map is optional (the batch pipeline does not read it).
+//
+// Arithmetic is the reference's, as in dcd_seg.hip: float32 distance sqrt((d0^2+d1^2)+d2^2) with a
+// strict '<' (evaluated literally only when two squared distances are within 2^-15 of each other),
+// integer sums, float32 centre = sum / count, float32 shift sums added in float64.
+#include "common.h"
+#include "../../include/imgan.h"
+#include "dcd_common.h"
+#include "dcd_lists.h"
+
+using namespace imgan_dcd;
+
+namespace {
+
+#ifdef IMGAN_TIER_TIMING
+// phase clocks of thread 0, summed over the segments (tools/tier_timing.py; never built into the
+// product): 100 MHz ticks per phase, [31] = segments
+__device__ unsigned long long tier_timing[32];
+#define TIER_MARK(i)                                                    \
+    if (tid == 0) {                                                     \
+        const unsigned long long now_ = wall_clock64();                 \
+        atomicAdd(&tier_timing[i], now_ - t_last_);                     \
+        t_last_ = now_;                                                 \
+    }
+#else
+#define TIER_MARK(i)
+#endif
+
+struct TierArgs {
+    const uint8_t* lab;
+    int H, W, nseg, k, use_hash;
+    uint32_t seed;
+    float* centres;
+    uint8_t* assign;                    // may be NULL: the map is not written
+    SegState* seg;
+    unsigned long long* stats;
+    const int* bbox;
+    int max_rounds;
+    SegLists L;
+    int tier, next_tier;                // list this launch works through / list for table overflows
+};
+
+// lanes that share an accumulator word (LDS atomics): a buffer is 1024 words either way
+__host__ __device__ constexpr int tier_copies(int km) { return 256 / km; }
+
+__host__ __device__ constexpr size_t tier_lds_bytes(int km, int cap) {
+    // table + counts + colour indices (6 B per pixel of capacity), two accumulator buffers,
+    // the 64-bit slots, 16 words of flags
+    return (size_t)cap * 6 + (size_t)2 * km * 4 * tier_copies(km) * 4 + (size_t)km * 8 + 64;
+}
+
+constexpr int tier_waves_per_simd(int km, int cap, int threads) {
+    return (threads / 256) * (int)((160 * 1024) / tier_lds_bytes(km, cap));
+}
+
+__device__ __forceinline__ float lane_f(float v, int j) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
+// One segment, start to finish, by the whole workgroup.
+template <int KM, int CAP, int THREADS>
+__device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArgs& A, const int gs) {
+    constexpr int TU = (CAP * 2 / 3) / 64 * 64;            // table slots: 4 TU + 2 TU + 2 CAP <= 6 CAP
+    constexpr int TS = 64;                                 // of which the last TS are not hashed to
+    constexpr int TH = TU - TS;
+    constexpr int ROWS = KM * 4;                           // {count, sum0, sum1, sum2} per cluster
+    constexpr int COPIES = tier_copies(KM);                // 32 (KM = 8) or 16
+    constexpr int BUF = ROWS * COPIES;                     // words per accumulator buffer: 1024
+    static_assert(BUF == 1024, "the fold takes 16 words per lane");
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);     // hash table, then dense colour | cluster << 24
+    uint16_t* ucnt = reinterpret_cast<uint16_t*>(tab + TU);
+    uint16_t* idx = ucnt + TU;                             // per pixel: slot, then dense index
+    uint32_t* acc = reinterpret_cast<uint32_t*>(idx + CAP);
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(acc + 2 * BUF);
+    int* flags = reinterpret_cast<int*>(slots + KM);
+    int& s_full = flags[0];
+    int& s_unique = flags[1];                              // ([2]: the ticket)
+    int& s_joins = flags[3];
+    int& s_stack = flags[4];
+
+    // This body runs in the ticket loop: without the fence the compiler computes everything that
+    // depends on the thread index alone (a few dozen LDS addresses) once, ahead of the loop, keeps
+    // it alive across the whole kernel and ends up reloading it from scratch memory before every
+    // use (the close-up of the table took 19 % of a segment's time that way).  The wave index is
+    // declared uniform, so that tests on it are scalar branches.
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = A.k, W = A.W, H = A.H;
+    const SegLists& L = A.L;
+    const int b = gs / A.nseg;
+    const int* bb = A.bbox + (size_t)gs * 4;
+    // clamped into the image: boxes may come from the caller
+    const int xmin = max(bb[0], 0), ymin = max(bb[1], 0);
+    const int xmax = min(bb[2], W - 1), ymax = min(bb[3], H - 1);
+    SegState st;
+    st.old_sum = 0.0;
+    st.done = 1;
+    st.rounds = 0;
+    st.handled = 1;
+    st.pending = 0;
+    unsigned long long* out = A.stats + (size_t)gs * k * 8;
+    const uint32_t run_at = L.offsets[gs];
+    const uint32_t run_n = min(L.ends[gs] - run_at, L.cursor[gs]);
+    if (xmax < xmin || ymax < ymin || run_n == 0) {        // segment id without pixels
+        if (tid == 0) A.seg[gs] = st;
+        for (int i = tid; i < k * 8; i += THREADS) out[i] = 0ull;
+        return;
+    }
+    const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
+    const int area = bw * bh;
+    const size_t img = (size_t)b * H * W;
+    const int n = (int)min(run_n, (uint32_t)CAP);
+#ifdef IMGAN_TIER_TIMING
+    unsigned long long t_last_ = wall_clock64();
+    if (tid == 0) atomicAdd(&tier_timing[31], 1ull);
+#endif
+
+    // ---- the segment's run into the colour table
+    if (tid == 0) s_full = 0, s_stack = 0;
+    if (tid < KM) slots[tid] = ~0ull;
+    for (int i = tid; i < TU / 4; i += THREADS)
+        reinterpret_cast<uint4*>(tab)[i] = make_uint4(NO_COLOUR, NO_COLOUR, NO_COLOUR, NO_COLOUR);
+    for (int i = tid; i < TU / 8; i += THREADS) reinterpret_cast<uint4*>(ucnt)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * BUF / 4; i += THREADS) reinterpret_cast<uint4*>(acc)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    TIER_MARK(0)
+    {
+        const bool kpow2 = (k & (k - 1)) == 0;
+        constexpr int LU = 4;                              // loads in flight per thread
+        for (int i0 = 0; i0 < n; i0 += THREADS * LU) {
+            // a table that has been given up is not worth the rest of the run
+            if (*reinterpret_cast<volatile int*>(&s_full)) break;
+            uint32_t v[LU], xy[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = min(i0 + u * THREADS + tid, n - 1);
+                v[u] = L.spix[run_at + i];
+                xy[u] = L.sxy[run_at + i];
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * THREADS + tid;
+                if (i >= n) continue;
+                // the colour's slot: double hashing (the step comes from the hash's low bits), which
+                // keeps the probe sequences short at the loads met here -- linear probing gave up
+                // (64 probes) on 8 % of the bench batch's segments at loads of 0.7 to 0.9.  A colour
+                // that still finds no slot takes one of the last TS slots as an entry of its own
+                // (entries may repeat a colour: the sums do not change); only when those are gone
+                // too is the segment handed on.
+                const uint32_t c = v[u] & 0xffffffu;
+                const uint32_t hc = mix32(c);
+                uint32_t slot = __umulhi(hc, (uint32_t)TH);
+                const uint32_t step = 1u + (hc & 62u);     // odd steps < 64 << TH
+                int probe = 0;
+                for (; probe < DEDUP_PROBES; ++probe) {
+                    const uint32_t seen = atomicCAS(&tab[slot], NO_COLOUR, c);
+                    if (seen == NO_COLOUR || seen == c) break;
+                    slot += step;
+                    slot -= slot >= (uint32_t)TH ? (uint32_t)TH : 0u;
+                }
+                if (probe == DEDUP_PROBES) {
+                    const int at = atomicAdd(&s_stack, 1);
+                    if (at < TS) {
+                        slot = (uint32_t)(TH + at);
+                        tab[slot] = c;
+                    } else {
+                        s_full = 1;
+                        slot = 0;
+                    }
+                }
+                idx[i] = (uint16_t)slot;
+                // two 16-bit counts per word; no carry: a count is at most n < 65536
+                atomicAdd(reinterpret_cast<uint32_t*>(ucnt) + (slot >> 1), 1u << ((slot & 1u) * 16u));
+                if (A.use_hash) {
+                    // stand-in for random.sample (:79): slot h % k goes to the smallest (h, p)
+                    const int x = min(max((int)(xy[u] & 0xffffu), xmin), xmax);
+                    const int y = min(max((int)(xy[u] >> 16), ymin), ymax);
+                    const uint32_t p = (uint32_t)(__mul24(y, W) + x);
+                    const uint32_t h = mix32(p * 0x9e3779b1u + A.seed);
+                    const unsigned long long key = ((unsigned long long)h << 32) | (unsigned long long)p;
+                    unsigned long long* sl = &slots[kpow2 ? (h & (uint32_t)(k - 1)) : h % (uint32_t)k];
+                    if (key < *sl) atomicMin(sl, key);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    TIER_MARK(1)
+    if (s_full) {
+        // more colours than the table holds: the next tier has a larger one; the last tier's list
+        // goes to the plain body (dcd_seg.hip)
+        if (tid == 0) {
+            const int at = atomicAdd(&L.hdr[A.next_tier], 1);
+            L.tier[A.next_tier][at] = gs;
+        }
+        return;
+    }
+    // ---- close the table up.  Every thread takes TC consecutive slots (colour and count) into
+    // registers; a running sum of the occupied ones over the block gives every colour its dense
+    // index, left in its slot for the moment; the pixels swap their slot for the index; the
+    // colours and counts move to their dense places.
+    {
+        constexpr int TC = (TU + THREADS - 1) / THREADS;
+        uint32_t* wsum = acc;                              // a few words of a buffer cleared again below
+        uint32_t held[TC], occupied = 0;
+        uint16_t held_n[TC];
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+            const int slot = min(tid * TC + j, TU - 1);
+            held[j] = tab[slot];
+            held_n[j] = ucnt[slot];
+            if (tid * TC + j < TU && held[j] != NO_COLOUR) occupied |= 1u << j;
+        }
+        const int mine = __popc(occupied);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[wave] = (uint32_t)incl;
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int q = 0; q < THREADS / 64; ++q) {
+            const int ws = (int)wsum[q];
+            before += q < wave ? ws : 0;
+            total += ws;
+        }
+        const int first = before + incl - mine;
+        {
+            int id = first;
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+                if ((occupied >> j) & 1u) tab[tid * TC + j] = (uint32_t)id++;
+        }
+        if (tid == 0) s_unique = total;
+        __syncthreads();                                   // every slot holds its index now
+        if (tid < THREADS / 64) wsum[tid] = 0u;            // the accumulators start from zero
+        for (int i = tid; i < n; i += THREADS) idx[i] = (uint16_t)tab[idx[i]];
+        __syncthreads();
+        {
+            int id = first;
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+                if ((occupied >> j) & 1u) {
+                    tab[id] = held[j];
+                    ucnt[id] = held_n[j];
+                    ++id;
+                }
+        }
+        __syncthreads();
+    }
+    const int nloop = s_unique;
+    TIER_MARK(2)
+
+    // ---- Lloyd rounds (:85-107), one barrier each.  Lane layout of the per-round state: the
+    // 64 lanes of a wave cover the KM x 4 rows {count, sum0, sum1, sum2} of the accumulators, GL
+    // lanes per cluster and GL / 4 per row; lane (j, f) holds field f of cluster j after the fold
+    // and, for f = 1..3, component f - 1 of centre j, its previous value and its shift.
+    constexpr int GL = 64 / KM;                            // lanes per cluster: 8 (KM = 8), 4 (KM = 16)
+    constexpr int FL = GL / 4;                             // lanes per row
+    const int cj = lane / GL, cf = (lane / FL) & 3;        // this lane's cluster and field
+    const bool comp = cf >= 1 && cj < k && (lane & (FL - 1)) == 0;   // holds a centre component
+    float wc = 1.0e18f, wo = 0.f;                          // unused slots: far from every 8-bit colour,
+    {                                                      // so the loop over all KM never picks them
+        const int j = cj < k ? cj : 0, f = cf >= 1 ? cf - 1 : 0;
+        float v0;
+        if (A.use_hash) {
+            unsigned long long fallback = ~0ull;
+            for (int q = 0; q < k; ++q) fallback = slots[q] < fallback ? slots[q] : fallback;
+            const unsigned long long key = slots[j] != ~0ull ? slots[j] : fallback;
+            v0 = (float)A.lab[(img + (uint32_t)key) * 3 + f];
+        } else {
+            v0 = A.centres[((size_t)gs * k + j) * 3 + f];
+        }
+        if (comp) wc = v0;
+    }
+    double old_sum = 0.0;
+    int rounds = 0;
+    uint32_t field = 0;                                    // lane (j, f): field f of cluster j, last round
+    uint32_t seen0 = 0, seen1 = 0;                         // this lane's running totals of the two buffers
+    // a q within 2^-15 of the smallest one replays the literal rule (margins as in dcd_seg.hip)
+    const float NEAR = 1.0f - 3.0517578125e-05f;
+    constexpr uint32_t IDXM = KM - 1;
+    // The accumulators are never cleared: two buffers take the rounds in turn (nothing adds to a
+    // buffer while a wave may still be reading it: round r adds before barrier r, round r + 2
+    // after barrier r + 1, and the reads of round r lie between those two barriers), and a round's
+    // sums are the buffer's totals minus the totals this lane saw two rounds ago (mod 2^32).
+    int buf = 0;
+    const int copy = lane & (COPIES - 1);
+    while (true) {
+        float c0[KM], c1[KM], c2[KM];                      // scalars: the same in every lane
+#pragma unroll
+        for (int j = 0; j < KM; ++j) {
+            c0[j] = lane_f(wc, j * GL + FL);
+            c1[j] = lane_f(wc, j * GL + 2 * FL);
+            c2[j] = lane_f(wc, j * GL + 3 * FL);
+        }
+        uint32_t* ab = acc + buf * BUF + copy;
+        for (int i = tid; i < nloop; i += THREADS) {
+            const uint32_t v = tab[i];
+            const uint32_t weight = (uint32_t)ucnt[i];
+            const uint32_t u0 = v & 255u, u1 = (v >> 8) & 255u, u2 = (v >> 16) & 255u;
+            const float f0 = (float)u0, f1 = (float)u1, f2 = (float)u2;
+            // the first minimum of sqrt_rn(q) is the first minimum of q unless another q lies
+            // within a few ulp of the smallest: track the two smallest q (cluster index in the low
+            // mantissa bits), replay the literal rule on a near tie
+            uint32_t best = 0xffffffffu, second = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < KM; ++j) {
+                const float d0 = f0 - c0[j], d1 = f1 - c1[j], d2 = f2 - c2[j];
+                const float q = __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0));
+                const uint32_t kq = (__float_as_uint(q) & ~IDXM) | (uint32_t)j;
+                second = umed3(kq, best, second);
+                best = min(best, kq);
+            }
+            int bi = (int)(best & IDXM);
+            if (__builtin_expect(__fmul_rn(__uint_as_float(second), NEAR) < __uint_as_float(best), 0)) {
+                float bs = __builtin_inff();
+                bi = 0;
+#pragma unroll
+                for (int j = 0; j < KM; ++j)
+                    if (j < k) {
+                        const float e0 = __fsub_rn(f0, c0[j]), e1 = __fsub_rn(f1, c1[j]),
+                                    e2 = __fsub_rn(f2, c2[j]);
+                        const float sq = __fsqrt_rn(__fadd_rn(
+                            __fadd_rn(__fmul_rn(e0, e0), __fmul_rn(e1, e1)), __fmul_rn(e2, e2)));
+                        if (sq < bs) {
+                            bs = sq;
+                            bi = j;
+                        }
+                    }
+            }
+            tab[i] = (v & 0xffffffu) | ((uint32_t)bi << 24);
+            uint32_t* a4 = ab + bi * (4 * COPIES);
+            atomicAdd(a4, weight);
+            atomicAdd(a4 + COPIES, __umul24(weight, u0));
+            atomicAdd(a4 + 2 * COPIES, __umul24(weight, u1));
+            atomicAdd(a4 + 3 * COPIES, __umul24(weight, u2));
+        }
+        TIER_MARK(3)
+        __syncthreads();
+        TIER_MARK(4)
+        // ---- fold (every wave): a buffer is KM * 4 rows of COPIES words = 16 words per lane
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(acc + buf * BUF + lane * 16);
+            const uint4 p = src[0], q = src[1], r = src[2], t4 = src[3];
+            uint32_t tot = (((p.x + p.y) + (p.z + p.w)) + ((q.x + q.y) + (q.z + q.w))) +
+                           (((r.x + r.y) + (r.z + r.w)) + ((t4.x + t4.y) + (t4.z + t4.w)));
+            if (FL == 2) tot += (uint32_t)__builtin_amdgcn_mov_dpp((int)tot, 0xb1, 0xf, 0xf, true);   // lane ^ 1
+            if (buf == 0) {
+                field = tot - seen0;
+                seen0 = tot;
+            } else {
+                field = tot - seen1;
+                seen1 = tot;
+            }
+        }
+        const uint32_t nj = (uint32_t)__shfl((int)field, lane & ~(GL - 1));   // the cluster's count
+        // ---- empty clusters (:101), re-seeded by the whole block: the mask is the same in every
+        // wave.  Cluster j takes the segment's pixel with the smallest resample_key (dcd_common.h).
+        float drawn = wc;
+        const unsigned long long empty = __ballot(cj < k && (lane & (GL - 1)) == 0 && nj == 0);
+        if (empty) {
+            if (tid < KM) slots[tid] = ~0ull;
+            __syncthreads();
+            unsigned long long m = empty;
+            while (m) {
+                const int j = (__ffsll((long long)m) - 1) / GL;
+                m &= m - 1;
+                unsigned long long best = ~0ull;
+                for (int i = tid; i < n; i += THREADS) {
+                    const uint32_t xy = L.sxy[run_at + i];
+                    const int x = min(max((int)(xy & 0xffffu), xmin), xmax);
+                    const int y = min(max((int)(xy >> 16), ymin), ymax);
+                    const unsigned long long key = resample_key((uint32_t)(y * W + x), A.seed, j);
+                    best = key < best ? key : best;
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const unsigned long long other = __shfl_xor(best, o);
+                    best = other < best ? other : best;
+                }
+                if (lane == 0 && best != ~0ull) atomicMin(&slots[j], best);
+            }
+            __syncthreads();
+            if (comp && nj == 0) drawn = (float)A.lab[(img + (uint32_t)slots[cj]) * 3 + (cf - 1)];
+        }
+        // ---- centre update + stop rule (:93-107): one division for all components
+        float shift = 0.f;
+        if (comp) {
+            wc = nj ? __fdiv_rn((float)field, (float)nj) : drawn;      // or the re-sampled pixel (:101)
+            shift = fabsf(__fsub_rn(wc, wo));
+        }
+        // float32 sums in cluster order (:102): the shifts of component f move to lanes
+        // 16 f .. 16 f + KM - 1, a running sum along each row of 16 lanes adds them in order (after
+        // s steps the lanes up to s hold their exact prefix), lane 16 f + k - 1 has the total
+        const int from = (lane & 15) * GL + ((lane >> 4) + 1) * FL;
+        const float moved = __shfl(shift, from);            // every lane takes part: not under the test
+        const float x = ((lane >> 4) < 3 && (lane & 15) < k) ? moved : 0.f;
+        float run = x;
+#pragma unroll
+        for (int sft = 1; sft < KM; ++sft) {
+            const float up = __int_as_float(
+                __builtin_amdgcn_update_dpp(0, __float_as_int(run), 0x111, 0xf, 0xf, true));   // row_shr:1
+            run = __fadd_rn(up, x);
+        }
+        const float sh0 = lane_f(run, k - 1), sh1 = lane_f(run, 16 + k - 1), sh2 = lane_f(run, 32 + k - 1);
+        const double cent_sum = ((double)sh0 + (double)sh1) + (double)sh2;
+        rounds += 1;
+        const int stop = __builtin_amdgcn_readfirstlane(
+            (fabs(old_sum - cent_sum) < 0.1 || rounds >= A.max_rounds) ? 1 : 0);
+        TIER_MARK(5)
+        if (stop) break;
+        old_sum = cent_sum;
+        wo = wc;
+        buf ^= 1;
+    }
+
+    // the positions of this thread's pixels, wanted by the coherence pass: asked for now, all at
+    // once (clamped, not branched around), so that they arrive while the statistics are made
+    constexpr int NPT = CAP / THREADS;
+    static_assert(NPT * THREADS == CAP, "CAP must be a multiple of the block size");
+    uint32_t where[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) where[t] = L.sxy[run_at + min(tid + t * THREADS, n - 1)];
+
+    // ---- statistics (:110-116): counts and sums are the last round's, the squares need a pass
+    // over the distinct colours, weighted (a copy's sums stay below n * 255^2 < 2^32)
+    __syncthreads();                                       // every wave has left the rounds
+    for (int i = tid; i < KM * 3 * COPIES; i += THREADS) acc[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < nloop; i += THREADS) {
+        const uint32_t v = tab[i], weight = ucnt[i];
+        const uint32_t u0 = v & 255u, u1 = (v >> 8) & 255u, u2 = (v >> 16) & 255u, bi = v >> 24;
+        uint32_t* a3 = acc + bi * (3 * COPIES) + copy;
+        atomicAdd(a3, weight * (u0 * u0));
+        atomicAdd(a3 + COPIES, weight * (u1 * u1));
+        atomicAdd(a3 + 2 * COPIES, weight * (u2 * u2));
+    }
+    __syncthreads();
+    if (tid < k * 3) {
+        const uint4* src = reinterpret_cast<const uint4*>(acc + tid * COPIES);
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int t = 0; t < COPIES / 4; ++t) {
+            const uint4 w4 = src[t];
+            sum += (unsigned long long)w4.x + w4.y + w4.z + w4.w;
+        }
+        out[(tid / 3) * 8 + 4 + (tid % 3)] = sum;
+    }
+    if (wave == 0 && cj < k && (lane & (FL - 1)) == 0) {
+        out[cj * 8 + cf] = field;                          // count, sum0, sum1, sum2 of the last round
+        if (cf >= 1) A.centres[((size_t)gs * k + cj) * 3 + (cf - 1)] = wc;
+    }
+
+    TIER_MARK(6)
+    // ---- spatial coherence (:40-74, :118-127): largest 8-connected component of every cluster,
+    // found on chip.  Each thread takes its pixels (cell in the box, cluster) into registers -- the
+    // positions come from the list again --; the table's place is then reused as a grid over the
+    // box: first the cluster of every cell (u8), from which each cell picks its link (kept in its
+    // register as a direction), then, in the same place, the parents (u16).
+    const float inv_bw = 1.0f / (float)bw;
+    uint32_t keep[NPT];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int i = tid + t * THREADS;
+        keep[t] = 0xffffffffu;
+        if (i < n) {
+            const uint32_t xy = where[t];
+            const int x = min(max((int)(xy & 0xffffu), xmin), xmax);
+            const int y = min(max((int)(xy >> 16), ymin), ymax);
+            const uint32_t cl = tab[idx[i]] >> 24;
+            keep[t] = (uint32_t)(__mul24(y - ymin, bw) + (x - xmin)) | (cl << 16);
+            if (A.assign) A.assign[img + (size_t)(uint32_t)(__mul24(y, W) + x)] = (uint8_t)cl;
+        }
+    }
+    TIER_MARK(7)
+    uint16_t* par = reinterpret_cast<uint16_t*>(smem);
+    uint8_t* cls = smem;
+    uint32_t* largest = reinterpret_cast<uint32_t*>(slots);
+    __syncthreads();
+    for (int i = tid; i < (area + 3) / 4; i += THREADS) reinterpret_cast<uint32_t*>(cls)[i] = 0xffffffffu;
+    if (tid < KM) largest[tid] = 0;
+    // the cells that need an explicit union below, collected in the accumulators' place
+    uint16_t* joins = reinterpret_cast<uint16_t*>(acc);
+    constexpr int JOINS = 2 * BUF * 2;
+    if (tid == 0) s_joins = 0;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu) cls[keep[t] & 0xffffu] = (uint8_t)(keep[t] >> 16);
+    __syncthreads();
+    // Every cell hangs itself under one earlier neighbour of its cluster (N, else W, else NW, else
+    // NE; all have a smaller index, so the links form a forest) with a plain store.  Of the four
+    // backward links only one more can be needed: with N present the others follow from the
+    // neighbours' own links, and W covers NW; what is left is NE next to a missing N, which is
+    // united explicitly below.  Those cells go on a list that the whole block works through evenly.
+    // (Bit 25: no room on the list.)
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        bool join = false;
+        if (keep[t] != 0xffffffffu) {
+            const uint32_t cell = keep[t] & 0xffffu;
+            const uint8_t c = (uint8_t)(keep[t] >> 16);
+            int yy = (int)((float)cell * inv_bw);
+            int xx = (int)cell - __mul24(yy, bw);
+            yy += (xx >= bw) - (xx < 0);
+            xx = (int)cell - __mul24(yy, bw);
+            const bool up = yy > 0, lf = xx > 0, rt = xx < bw - 1;
+            const bool n_ = up && cls[cell - bw] == c, w_ = lf && cls[cell - 1] == c;
+            const bool nw = up && lf && cls[cell - bw - 1] == c;
+            const bool ne = up && rt && cls[cell - bw + 1] == c;
+            // bits 26-28: 0 self, 1 N, 2 W, 3 NW, 4 NE
+            keep[t] |= (n_ ? 1u : w_ ? 2u : nw ? 3u : ne ? 4u : 0u) << 26;
+            join = !n_ && (w_ || nw) && ne;
+        }
+        if (join) {
+            const int at = atomicAdd(&s_joins, 1);
+            if (at < JOINS)
+                joins[at] = (uint16_t)(keep[t] & 0xffffu);
+            else
+                keep[t] |= 0x2000000u;
+        }
+    }
+    __syncthreads();                                       // every cluster byte has been read
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu) {
+            const uint32_t cell = keep[t] & 0xffffu, dir = (keep[t] >> 26) & 7u;
+            const uint32_t link = dir == 1u ? cell - bw : dir == 2u ? cell - 1 : dir == 3u ? cell - bw - 1
+                                                        : dir == 4u ? cell - bw + 1 : cell;
+            par[cell] = (uint16_t)link;
+        }
+    __syncthreads();
+    for (int e = tid, ne_ = min(s_joins, JOINS); e < ne_; e += THREADS) {
+        const uint32_t cell = joins[e];
+        unite16(par, cell, cell - bw + 1);
+    }
+    if (s_joins > JOINS) {
+#pragma unroll
+        for (int t = 0; t < NPT; ++t)
+            if (keep[t] != 0xffffffffu && (keep[t] & 0x2000000u)) {
+                const uint32_t cell = keep[t] & 0xffffu;
+                unite16(par, cell, cell - bw + 1);
+            }
+    }
+    __syncthreads();
+    // roots into registers (bit 24: this cell is a root), then the parent grid turns into 16-bit
+    // size counters (two per word; a segment has < 65536 pixels, so no carry)
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu) {
+            const uint32_t cell = keep[t] & 0xffffu;
+            const uint32_t root = find16(par, cell);
+            par[cell] = (uint16_t)root;                    // shortens the walks of later cells
+            keep[t] = root | (keep[t] & 0xff0000u) | (root == cell ? 0x1000000u : 0u);
+        }
+    __syncthreads();
+    for (int i = tid; i < (area + 1) / 2; i += THREADS) reinterpret_cast<uint32_t*>(par)[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu) {
+            const uint32_t root = keep[t] & 0xffffu;
+            atomicAdd(reinterpret_cast<uint32_t*>(par) + (root >> 1), 1u << ((root & 1u) * 16u));
+        }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu && (keep[t] & 0x1000000u))
+            atomicMax(&largest[(keep[t] >> 16) & 0xffu], (uint32_t)par[keep[t] & 0xffffu]);
+    __syncthreads();
+    TIER_MARK(8)
+    if (tid < k) out[tid * 8 + 7] = largest[tid];
+    if (tid == 0) {
+        st.rounds = rounds;
+        A.seg[gs] = st;
+    }
+}
+
+template <int KM, int CAP, int THREADS>
+__global__ __launch_bounds__(THREADS, tier_waves_per_simd(KM, CAP, THREADS))
+void dcd_dedup_kernel(TierArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // the workgroups draw tickets for the entries of their list: segments differ in size and in
+    // rounds by an order of magnitude, so a fixed split would leave a long tail
+    int* ticket = reinterpret_cast<int*>(smem + tier_lds_bytes(KM, CAP) - 64) + 2;
+    const int count = A.L.hdr[A.tier];
+    while (true) {
+        if (threadIdx.x == 0) *ticket = atomicAdd(&A.L.hdr[8 + A.tier], 1);
+        __syncthreads();
+        const int e = __builtin_amdgcn_readfirstlane(*ticket);
+        __syncthreads();
+        if (e >= count) break;
+        const int gs = __builtin_amdgcn_readfirstlane(A.L.tier[A.tier][e]);
+        dedup_segment<KM, CAP, THREADS>(smem, A, gs);
+        __syncthreads();
+    }
+}
+
+template <int KM, int CAP, int THREADS>
+int launch(const TierArgs& A, size_t nsegs, int per_cu, hipStream_t st) {
+    const size_t lds = tier_lds_bytes(KM, CAP);
+    auto fn = dcd_dedup_kernel<KM, CAP, THREADS>;
+    IMGAN_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)std::min<size_t>(nsegs, (size_t)256 * per_cu);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(THREADS), lds, st, A);
+    return 0;
+}
+
+}  // namespace
+
+#ifdef IMGAN_TIER_TIMING
+extern "C" int imgan_debug_tier_timing(unsigned long long* out32, int reset) {
+    IMGAN_HIP(hipDeviceSynchronize());
+    IMGAN_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(tier_timing), 256));
+    if (reset) {
+        unsigned long long z[32] = {0};
+        IMGAN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(tier_timing), z, 256));
+    }
+    return 0;
+}
+#endif
+
+// The tier launches of imgan_dcd_segments_listed, smallest tier first: a segment whose colours
+// overflow a tier's table moves to the next tier's list, and from the last tier to list 3, which
+// the caller hands to the plain body.  Lists and counters are those of seg_plan_kernel.
+int imgan_dcd_launch_dedup_tiers(const uint8_t* lab, int B, int H, int W, int nseg, int k, int use_hash,
+                                 uint32_t seed, float* centres, uint8_t* assign, SegState* seg,
+                                 unsigned long long* stats, const int* bbox, int max_rounds,
+                                 const SegLists& L, hipStream_t st) {
+    TierArgs A;
+    A.lab = lab;
+    A.H = H, A.W = W, A.nseg = nseg, A.k = k, A.use_hash = use_hash;
+    A.seed = seed;
+    A.centres = centres;
+    A.assign = assign;
+    A.seg = seg;
+    A.stats = stats;
+    A.bbox = bbox;
+    A.max_rounds = max_rounds;
+    A.L = L;
+    const size_t nsegs = (size_t)B * nseg;
+    if (k <= 8) {
+        A.tier = 0, A.next_tier = 1;
+#ifndef TIER_T0
+#define TIER_T0 THREADS_TINY
+#endif
+#ifndef TIER_T1
+#define TIER_T1 THREADS_SMALL
+#endif
+        if (int rc = launch<8, CAP_TINY_D, TIER_T0>(A, nsegs, 3, st)) return rc;
+        A.tier = 1, A.next_tier = 2;
+        if (int rc = launch<8, CAP_SMALL_D, TIER_T1>(A, nsegs, 2, st)) return rc;
+        A.tier = 2, A.next_tier = 3;
+        if (int rc = launch<8, CAP_LARGE, THREADS_LARGE>(A, nsegs, 1, st)) return rc;
+    } else {
+        A.tier = 1, A.next_tier = 2;
+        if (int rc = launch<16, CAP_SMALL_K16, THREADS_SMALL>(A, nsegs, 2, st)) return rc;
+        A.tier = 2, A.next_tier = 3;
+        if (int rc = launch<16, CAP_LARGE, THREADS_LARGE>(A, nsegs, 1, st)) return rc;
+    }
+    return 0;
+}

@@ -493,7 +493,7 @@ class DcdPlan(object):
 
     def kmeans(self, lab, labels, centres, seed=None, max_rounds=1000, check_every=1,
                streaming_only=False, boxed=False, max_segment_px=None, counted=False,
-               resample_seed=0):
+               resample_seed=0, write_assign=True):
         """Runs every segment's Lloyd loop to the reference's stop rule.
         centres: float32 [B,nseg,k,3], updated in place; with seed is not None they are
         sampled on the device (hash rule of imgan_dcd_init_hash), otherwise they must hold
@@ -504,6 +504,9 @@ class DcdPlan(object):
         seed the same value serves both.
         counted: self.counts already holds the pixel count of every segment
         (SlicPlan.label_counts(out=self.counts)); counted otherwise (plans with lists only).
+        write_assign: False leaves self.assign unwritten by the on-chip pass (the descriptor
+        rows do not need the per-pixel map; pixel lists only).  Segments that end up in the
+        streaming rounds write their part of it all the same.
         max_segment_px: the size the caller expects no segment to exceed (a SLIC superpixel
         normally lies inside its centre's 2S x 2S window, slic.py:94-100).  When it is within the
         on-chip capacity the count of segments left for the streaming rounds is not read back
@@ -537,7 +540,8 @@ class DcdPlan(object):
                                                  _ptr(self.counts), _stream()))
                 check(lib.imgan_dcd_segments_listed(
                     _ptr(lab), _ptr(labels), *shape, 1 if use_hash else 0, cseed, _ptr(centres),
-                    _ptr(self.assign), _ptr(self.state), _ptr(self.stats), _ptr(self.bbox),
+                    _ptr(self.assign) if write_assign else None, _ptr(self.state), _ptr(self.stats),
+                    _ptr(self.bbox),
                     _ptr(self.counts), _ptr(self.list_scratch), _ptr(self.n_big), int(max_rounds),
                     _stream()))
             else:

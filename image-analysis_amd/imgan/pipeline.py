@@ -16,9 +16,11 @@ from ._lib import lib, check
 class FullPipeline(object):
     def __init__(self, B, H, W, num_clusters, colour_weight=15, num_iter=10, dominant=8,
                  csd_bins=256, dcd_seed=12345, dcd_check_every=4, dcd_max_rounds=200,
-                 per_region=False):
+                 per_region=False, want_assign=False):
         """per_region: colour layout / edge histogram / colour structure of every superpixel
-        (configs[4]) instead of the whole image."""
+        (configs[4]) instead of the whole image.  want_assign: also write the per-pixel
+        dominant-colour index map (self.dcd.assign), which the descriptor rows do not need."""
+        self.want_assign = bool(want_assign)
         self.B, self.H, self.W = int(B), int(H), int(W)
         self.cw, self.num_iter, self.k = colour_weight, int(num_iter), int(dominant)
         self.seed, self.check_every, self.max_rounds = dcd_seed, dcd_check_every, dcd_max_rounds
@@ -81,7 +83,7 @@ class FullPipeline(object):
                 self.lab, labels, self.centres, seed=self.seed, max_rounds=self.max_rounds,
                 check_every=self.check_every, boxed=getattr(self, "boxed", False),
                 counted=getattr(self, "boxed", False) and self.dcd.lists,
-                max_segment_px=(2 * self.slic.S) ** 2))
+                max_segment_px=(2 * self.slic.S) ** 2, write_assign=self.want_assign))
             self.dcd_rounds_run = self.dcd.rounds_run
             stats = self.dcd.statistics(self.lab, labels)
             check(lib.imgan_dcd_features(p(stats), p(self.centres), self.B, self.n, self.k,

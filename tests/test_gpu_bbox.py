@@ -80,7 +80,7 @@ def test_dominant_colours_with_given_boxes_equal_the_plain_call():
     B, H, W, K = 3, 216, 384, 60
     img = np.stack([voronoi_image(H, W, 20, seed=70 + b) for b in range(B)])
     bgr = torch.from_numpy(img).cuda()
-    pipe = FullPipeline(B, H, W, K)
+    pipe = FullPipeline(B, H, W, K, want_assign=True)
     pipe.run_slic(bgr)
     assert pipe.boxed
     pipe.run_dcd()
@@ -100,7 +100,7 @@ def test_boxes_beyond_the_image_are_clamped():
     B, H, W, K = 2, 216, 384, 60
     img = np.stack([voronoi_image(H, W, 20, seed=80 + b) for b in range(B)])
     bgr = torch.from_numpy(img).cuda()
-    pipe = FullPipeline(B, H, W, K)
+    pipe = FullPipeline(B, H, W, K, want_assign=True)
     pipe.run_slic(bgr)
     pipe.run_dcd()
     feats, assign, stats = pipe.features.clone(), pipe.dcd.assign.clone(), pipe.dcd.stats.clone()

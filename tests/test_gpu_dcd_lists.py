@@ -287,7 +287,7 @@ def test_step_outputs_do_not_depend_on_the_run():
     from bench import synth_batch
     from imgan.pipeline import FullPipeline
     bgr = synth_batch(4, 1080, 1920, 400, 77, "cuda")
-    pipe = FullPipeline(4, 1080, 1920, 400)
+    pipe = FullPipeline(4, 1080, 1920, 400, want_assign=True)
     ref = None
     for _ in range(3):
         rows, feats = pipe.step(bgr)

@@ -212,8 +212,16 @@ def test_1080p_full_pipeline_hash_init_against_c_oracle():
     from oracle.dcd_ref import mix32
     H, W, K, k, seed = 1080, 1920, 400, 8, 12345
     img = voronoi_image(H, W, K, seed=1081)
-    pipe = FullPipeline(1, H, W, K, dominant=k, dcd_seed=seed)
-    rows, feats = pipe.step(torch.from_numpy(img).cuda().unsqueeze(0))
+    dev_img = torch.from_numpy(img).cuda().unsqueeze(0)
+    # bench.py's form writes no per-pixel assignment map; the same step with the map asked for must
+    # give the same rows, and it is that map the per-pixel comparison below reads
+    bare = FullPipeline(1, H, W, K, dominant=k, dcd_seed=seed)
+    rows0, feats0 = bare.step(dev_img)
+    rows0, feats0 = rows0.clone(), feats0.clone()
+    del bare
+    pipe = FullPipeline(1, H, W, K, dominant=k, dcd_seed=seed, want_assign=True)
+    rows, feats = pipe.step(dev_img)
+    assert torch.equal(rows, rows0) and torch.equal(feats.view(torch.int32), feats0.view(torch.int32))
     assert pipe.dcd.lists and int(pipe.dcd.n_big.item()) == 0
     lab_np = bgr2lab_u8(img)
     want_labels, _ = c_oracle.slic_run(lab_np, K, 15, 10)

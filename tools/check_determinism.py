@@ -10,7 +10,7 @@ from imgan.pipeline import FullPipeline
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 bgr = synth_batch(B, 1080, 1920, 400, 1234, "cuda")
-pipe = FullPipeline(B, 1080, 1920, 400)
+pipe = FullPipeline(B, 1080, 1920, 400, want_assign=True)
 ref = None
 bad = 0
 for r in range(reps):
