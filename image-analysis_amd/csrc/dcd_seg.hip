@@ -405,82 +405,27 @@ __device__ __noinline__ void resample_empty(unsigned long long empty, const uint
     __builtin_amdgcn_wave_barrier();
 }
 
-// The same for MODE_DEDUP, where LDS holds colours and colour indices: the positions come from the
-// segment's run of the list again.
-__device__ __noinline__ void resample_empty_listed(unsigned long long empty, const uint32_t* colours,
-                                                   const uint16_t* idx, const uint32_t* sxy, int n,
-                                                   int xmin, int ymin, int xmax, int ymax, int W,
-                                                   uint32_t seed, float* cen, int stride) {
-    const int lane = threadIdx.x & 63;
-    while (empty) {
-        const int j = __ffsll((long long)empty) - 1;
-        empty &= empty - 1;
-        unsigned long long best = ~0ull;
-        uint32_t colour = 0;
-        for (int i = lane; i < n; i += 64) {
-            const uint32_t xy = sxy[i];
-            const int x = min(max((int)(xy & 0xffffu), xmin), xmax);
-            const int y = min(max((int)(xy >> 16), ymin), ymax);
-            const unsigned long long key = resample_key((uint32_t)(y * W + x), seed, j);
-            if (key < best) {
-                best = key;
-                colour = colours[idx[i]] & 0xffffffu;
-            }
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const unsigned long long other = __shfl_xor(best, o);
-            const uint32_t other_colour = (uint32_t)__shfl_xor((int)colour, o);
-            if (other < best) {
-                best = other;
-                colour = other_colour;
-            }
-        }
-        if (lane == 0 && best != ~0ull) {
-            cen[j] = (float)(colour & 255u);
-            cen[stride + j] = (float)((colour >> 8) & 255u);
-            cen[2 * stride + j] = (float)((colour >> 16) & 255u);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
 // One segment, start to finish, by the whole workgroup.  MODE_FIRST: the small tier visits every
 // segment, gathers its pixels from its bounding box and puts those that do not fit on the retry
 // list; MODE_RETRY: the large tier works through that list and counts what is still too large
 // (left to the streaming path); MODE_LISTED: the pixels come from the segment's run of the pixel
 // lists, and the plan kernel has already chosen a tier that holds them.
-//
-// MODE_DEDUP is MODE_LISTED on the distinct colours of the segment: the assignment of a pixel
-// depends on its colour alone and the sums are integers, so the Lloyd rounds can run over one
-// entry per distinct colour, weighted by the number of pixels that have it -- the same centres,
-// assignments and rounds at a fraction of the distance evaluations (0.41 distinct colours per pixel
-// on the bench batch).  The colours are collected in an LDS hash table while the run is loaded,
-// closed up into dense arrays {colour | cluster << 24, count}, and every pixel keeps the index of
-// its colour (2 B) in the place of its box offset, which is read again from the list where the
-// statistics and the coherence pass need it.  A segment whose colours do not fit the table is
-// handed back (false) and the workgroup runs the MODE_LISTED body on it.  (Sending segments below
-// 3072 or 4608 pixels straight to the plain body was measured: slower than the table for all.)
-constexpr int MODE_FIRST = 0, MODE_RETRY = 1, MODE_LISTED = 2, MODE_DEDUP = 3;
+// (The dedup tiers, which run the rounds over the distinct colours of a segment, are dcd_tiers.hip;
+// a segment whose colours fit none of their tables comes here, MODE_LISTED on list 3.)
+constexpr int MODE_FIRST = 0, MODE_RETRY = 1, MODE_LISTED = 2;
 
 template <int KM, int CAP, int THREADS, int MODE>
-__device__ __forceinline__ bool segment_body(
+__device__ __forceinline__ void segment_body(
     unsigned char* smem, const int b, const int s, const int B, const uint8_t* __restrict__ lab,
     const int32_t* __restrict__ labels, int H, int W, int nseg, int k, int use_hash, uint32_t seed,
     float* __restrict__ centres, uint8_t* __restrict__ assign, SegState* __restrict__ seg,
     unsigned long long* __restrict__ stats, const int* __restrict__ bbox, int* __restrict__ retry,
     int* __restrict__ big_count, int max_rounds, const SegLists& L, int tier) {
     constexpr bool FIRST = MODE == MODE_FIRST;
-    constexpr bool DEDUP = MODE == MODE_DEDUP;
-    constexpr bool LISTED = MODE == MODE_LISTED || DEDUP;
-    // DEDUP: pix = the colour table (TU slots), then the dense colour array; ucnt = the count of
-    // every colour; idx = every pixel's colour index: 4 TU + 2 TU + 2 CAP <= 6 CAP bytes
-    constexpr int TU = DEDUP ? (CAP * 2 / 3) / 64 * 64 : 64;
+    constexpr bool LISTED = MODE == MODE_LISTED;
     uint32_t* pix = reinterpret_cast<uint32_t*>(smem);                    // Lab | assign << 24
     uint16_t* pos = reinterpret_cast<uint16_t*>(pix + CAP);               // offset in the bbox
-    uint16_t* ucnt = reinterpret_cast<uint16_t*>(pix + TU);
-    uint16_t* idx = ucnt + TU;
-    constexpr bool PACKED = !DEDUP && (CAP / 64) * 255 < 65536;
+    constexpr bool PACKED = (CAP / 64) * 255 < 65536;
     constexpr int WORDS = PACKED ? 2 : 4;                                 // per cluster and copy
     constexpr int ACCW = WORDS > 3 ? WORDS : 3;                           // statistics use 3
     uint32_t* acc = reinterpret_cast<uint32_t*>(pos + CAP);               // [KM*ACCW][64] lane-private
@@ -492,7 +437,6 @@ __device__ __forceinline__ bool segment_body(
     int* flags = reinterpret_cast<int*>(sbuf + KM * 3);                   // no static LDS: keeps
     int& s_n = flags[0];                                                  // the dynamic base 16-B aligned
     int& s_done = flags[1];
-    int& s_unique = flags[3];                                             // ([2]: the ticket)
 
     const size_t gs = (size_t)b * nseg + s;
     int tid_ = threadIdx.x;
@@ -507,7 +451,7 @@ __device__ __forceinline__ bool segment_body(
 #ifdef IMGAN_SEG_TIMING
     unsigned long long t_last_ = wall_clock64();
 #endif
-    if (MODE == MODE_RETRY && seg[gs].handled) return true;
+    if (MODE == MODE_RETRY && seg[gs].handled) return;
     const int* bb = bbox + gs * 4;
     // clamped into the image: the boxes may come from the caller (imgan_dcd_segments_boxed), and a
     // box outside the image must not turn into a read outside the buffers
@@ -528,7 +472,7 @@ __device__ __forceinline__ bool segment_body(
     if (xmax < xmin || ymax < ymin || (LISTED && run_n == 0)) {   // segment id without pixels
         if (tid == 0) seg[gs] = st;
         for (int i = tid; i < k * 8; i += THREADS) out[i] = 0ull;
-        return true;
+        return;
     }
     const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
     const int area = bw * bh;
@@ -541,20 +485,14 @@ __device__ __forceinline__ bool segment_body(
         // and counts come from the caller -- must not turn into an offset outside the cell grid.)
         if (tid == 0) {
             s_n = (int)min(run_n, (uint32_t)CAP);
-            s_done = 0;                                 // DEDUP: raised when the colour table is full
+            s_done = 0;
         }
         if (tid < KM) slots[tid] = ~0ull;
-        if (DEDUP) {
-            for (int i = tid; i < TU; i += THREADS) pix[i] = NO_COLOUR;
-            for (int i = tid; i < TU / 2; i += THREADS) reinterpret_cast<uint32_t*>(ucnt)[i] = 0u;
-        }
         __syncthreads();
         const int nrun = (int)min(run_n, (uint32_t)CAP);
         const bool kpow2 = (k & (k - 1)) == 0;
         constexpr int LU = 4;                          // loads in flight per thread (8 and 16 measured: no gain)
         for (int i0 = 0; i0 < nrun; i0 += THREADS * LU) {
-            // a table that has been given up is not worth the rest of the run
-            if (DEDUP && *reinterpret_cast<volatile int*>(&s_done)) break;
             uint32_t v[LU], xy[LU];
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
@@ -568,24 +506,8 @@ __device__ __forceinline__ bool segment_body(
                 if (i >= nrun) continue;
                 const int x = min(max((int)(xy[u] & 0xffffu), xmin), xmax);
                 const int y = min(max((int)(xy[u] >> 16), ymin), ymax);
-                if (DEDUP) {
-                    // the colour's slot: linear probing from a multiplicative hash
-                    const uint32_t c = v[u] & 0xffffffu;
-                    uint32_t slot = __umulhi(mix32(c), (uint32_t)TU);
-                    int probe = 0;
-                    for (; probe < DEDUP_PROBES; ++probe) {
-                        const uint32_t seen = atomicCAS(&pix[slot], NO_COLOUR, c);
-                        if (seen == NO_COLOUR || seen == c) break;
-                        slot = slot + 1 == (uint32_t)TU ? 0u : slot + 1;
-                    }
-                    if (probe == DEDUP_PROBES) s_done = 1;
-                    idx[i] = (uint16_t)slot;
-                    // two 16-bit counts per word; no carry: a count is at most n < 65536
-                    atomicAdd(reinterpret_cast<uint32_t*>(ucnt) + (slot >> 1), 1u << ((slot & 1u) * 16u));
-                } else {
-                    pix[i] = v[u] & 0xffffffu;
-                    pos[i] = (uint16_t)(__mul24(y - ymin, bw) + (x - xmin));
-                }
+                pix[i] = v[u] & 0xffffffu;
+                pos[i] = (uint16_t)(__mul24(y - ymin, bw) + (x - xmin));
                 if (use_hash) {
                     const uint32_t p = (uint32_t)(__mul24(y, W) + x);
                     const uint32_t h = mix32(p * 0x9e3779b1u + seed);
@@ -599,60 +521,6 @@ __device__ __forceinline__ bool segment_body(
         __syncthreads();
         SEG_MARK(1)
         big = false;
-        if (DEDUP) {
-            if (s_done) return false;                   // too many colours: the caller runs the plain body
-            // ---- close the table up.  Every thread takes TC consecutive slots (colour and count)
-            // into registers; a running sum of the occupied ones over the block gives every colour
-            // its dense index, left in its slot for the moment; the pixels swap their slot for the
-            // index; the colours and counts move to their dense places.
-            constexpr int TC = (TU + THREADS - 1) / THREADS;
-            uint32_t held[TC], occupied = 0;
-            uint16_t held_n[TC];
-#pragma unroll
-            for (int j = 0; j < TC; ++j) {
-                const int slot = min(tid * TC + j, TU - 1);
-                held[j] = pix[slot];
-                held_n[j] = ucnt[slot];
-                if (tid * TC + j < TU && held[j] != NO_COLOUR) occupied |= 1u << j;
-            }
-            const int mine = __popc(occupied);
-            int incl = mine;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int up = __shfl_up(incl, o);
-                if (lane >= o) incl += up;
-            }
-            if (lane == 63) red[wave] = (uint32_t)incl;  // red: free until the first fold
-            __syncthreads();
-            int before = 0, total = 0;
-            for (int q = 0; q < THREADS / 64; ++q) {
-                const int ws = (int)red[q];
-                before += q < wave ? ws : 0;
-                total += ws;
-            }
-            const int first = before + incl - mine;
-            {
-                int id = first;
-#pragma unroll
-                for (int j = 0; j < TC; ++j)
-                    if ((occupied >> j) & 1u) pix[tid * TC + j] = (uint32_t)id++;
-            }
-            if (tid == 0) s_unique = total;
-            __syncthreads();                            // every slot holds its index now
-            for (int i = tid; i < nrun; i += THREADS) idx[i] = (uint16_t)pix[idx[i]];
-            __syncthreads();
-            {
-                int id = first;
-#pragma unroll
-                for (int j = 0; j < TC; ++j)
-                    if ((occupied >> j) & 1u) {
-                        pix[id] = held[j];
-                        ucnt[id] = held_n[j];
-                        ++id;
-                    }
-            }
-            __syncthreads();
-        }
     } else if (!big) {
         if (tid == 0) s_n = 0;
         if (tid < KM) slots[tid] = ~0ull;
@@ -730,7 +598,7 @@ __device__ __forceinline__ bool segment_body(
         if (!big && s_n == 0) {                         // a box (the caller's) without the label in it
             if (tid == 0) seg[gs] = st;
             for (int i = tid; i < k * 8; i += THREADS) out[i] = 0ull;
-            return true;
+            return;
         }
     }
     if (big) {                                          // too large for this tier
@@ -743,10 +611,10 @@ __device__ __forceinline__ bool segment_body(
             else
                 atomicAdd(big_count, 1);                         // left to the streaming path
         }
-        return true;
+        return;
     }
     const int n = s_n;
-    const int nloop = DEDUP ? s_unique : n;             // entries the rounds walk
+    const int nloop = n;
 
     // ---- initial centres
     if (tid < k) {
@@ -808,7 +676,7 @@ __device__ __forceinline__ bool segment_body(
         }
         for (int i = tid; i < nloop; i += THREADS) {
             const uint32_t v = pix[i];
-            const uint32_t weight = DEDUP ? (uint32_t)ucnt[i] : 1u;
+            const uint32_t weight = 1u;
             const uint32_t u0 = v & 255u, u1 = (v >> 8) & 255u, u2 = (v >> 16) & 255u;
             const float f0 = (float)u0, f1 = (float)u1, f2 = (float)u2;
             // The reference compares sqrt-rounded distances with '<' (:88-91): the winner is the
@@ -858,7 +726,7 @@ __device__ __forceinline__ bool segment_body(
         }
         __syncthreads();
         SEG_MARK(2)
-        if (wave == 0 && (PACKED || DEDUP)) {
+        if (wave == 0 && PACKED) {
             // ---- the serial section of a round, kept in registers: every dependent LDS access
             // here costs a few hundred cycles under the other workgroup's traffic, and eleven
             // waves wait for this one.  Reduce the 64 lane-private copies (4 lanes per
@@ -866,85 +734,47 @@ __device__ __forceinline__ bool segment_body(
             // quad permutes), hand cluster j's {count, sum0} / {sum1, sum2} rows to lane j with
             // one permute each, and add the shifts up from lane reads.
             uint32_t nj = 0, s0 = 0, s1 = 0, s2 = 0;
-            if (DEDUP) {
-                // 32-bit sums (the weighted sums of the dedup mode outgrow 16 bits): four rows per
-                // cluster {count, sum0, sum1, sum2}, i.e. lanes 16 j' + 4 r of iteration j / 4
-                constexpr int IT4 = (KM * 4 + 15) / 16;
-                uint32_t sum[IT4];
+        constexpr int ITER = (KM * 2 + 15) / 16;
+        uint32_t lo[ITER], hi[ITER];
 #pragma unroll
-                for (int it = 0; it < IT4; ++it) {
-                    const int row = it * 16 + (lane >> 2), q = lane & 3;
-                    sum[it] = 0;
-                    if (row < k * 4) {
-                        uint4* src = reinterpret_cast<uint4*>(acc + row * 64 + q * 16);
+        for (int it = 0; it < ITER; ++it) {
+            const int row = it * 16 + (lane >> 2), q = lane & 3;
+            lo[it] = hi[it] = 0;
+            if (row < k * 2) {
+                uint4* src = reinterpret_cast<uint4*>(acc + row * 64 + q * 16);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const uint4 w4 = src[t];
-                            src[t] = make_uint4(0, 0, 0, 0);
-                            sum[it] += (w4.x + w4.y) + (w4.z + w4.w);
-                        }
-                    }
-                    sum[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)sum[it], 0xb1, 0xf, 0xf, true);
-                    sum[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)sum[it], 0x4e, 0xf, 0xf, true);
-                }
-                const int from = (lane & 3) * 16;
-#pragma unroll
-                for (int it = 0; it < IT4; ++it) {
-                    const uint32_t a_ = (uint32_t)__shfl((int)sum[it], from), b_ = (uint32_t)__shfl((int)sum[it], from + 4);
-                    const uint32_t c_ = (uint32_t)__shfl((int)sum[it], from + 8), d_ = (uint32_t)__shfl((int)sum[it], from + 12);
-                    if ((lane >> 2) == it) {
-                        nj = a_;
-                        s0 = b_;
-                        s1 = c_;
-                        s2 = d_;
-                    }
-                }
-            } else {
-            constexpr int ITER = (KM * 2 + 15) / 16;
-            uint32_t lo[ITER], hi[ITER];
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int row = it * 16 + (lane >> 2), q = lane & 3;
-                lo[it] = hi[it] = 0;
-                if (row < k * 2) {
-                    uint4* src = reinterpret_cast<uint4*>(acc + row * 64 + q * 16);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const uint4 w4 = src[t];
-                        src[t] = make_uint4(0, 0, 0, 0);
-                        lo[it] += (w4.x & 0xffffu) + (w4.y & 0xffffu) + (w4.z & 0xffffu) + (w4.w & 0xffffu);
-                        hi[it] += (w4.x >> 16) + (w4.y >> 16) + (w4.z >> 16) + (w4.w >> 16);
-                    }
-                }
-                lo[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[it], 0xb1, 0xf, 0xf, true);   // lanes ^ 1
-                hi[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)hi[it], 0xb1, 0xf, 0xf, true);
-                lo[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[it], 0x4e, 0xf, 0xf, true);   // lanes ^ 2
-                hi[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)hi[it], 0x4e, 0xf, 0xf, true);
-            }
-            // cluster j: rows 2j {count, sum0} and 2j + 1 {sum1, sum2}, i.e. lanes 8 j' and 8 j' + 4
-            // of iteration j / 8 (j' = j % 8)
-            const int srcl = (lane & 7) * 8;
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const uint32_t a_ = (uint32_t)__shfl((int)lo[it], srcl), b_ = (uint32_t)__shfl((int)hi[it], srcl);
-                const uint32_t c_ = (uint32_t)__shfl((int)lo[it], srcl + 4), d_ = (uint32_t)__shfl((int)hi[it], srcl + 4);
-                if ((lane >> 3) == it) {
-                    nj = a_;
-                    s0 = b_;
-                    s1 = c_;
-                    s2 = d_;
+                for (int t = 0; t < 4; ++t) {
+                    const uint4 w4 = src[t];
+                    src[t] = make_uint4(0, 0, 0, 0);
+                    lo[it] += (w4.x & 0xffffu) + (w4.y & 0xffffu) + (w4.z & 0xffffu) + (w4.w & 0xffffu);
+                    hi[it] += (w4.x >> 16) + (w4.y >> 16) + (w4.z >> 16) + (w4.w >> 16);
                 }
             }
+            lo[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[it], 0xb1, 0xf, 0xf, true);   // lanes ^ 1
+            hi[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)hi[it], 0xb1, 0xf, 0xf, true);
+            lo[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)lo[it], 0x4e, 0xf, 0xf, true);   // lanes ^ 2
+            hi[it] += (uint32_t)__builtin_amdgcn_mov_dpp((int)hi[it], 0x4e, 0xf, 0xf, true);
+        }
+        // cluster j: rows 2j {count, sum0} and 2j + 1 {sum1, sum2}, i.e. lanes 8 j' and 8 j' + 4
+        // of iteration j / 8 (j' = j % 8)
+        const int srcl = (lane & 7) * 8;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const uint32_t a_ = (uint32_t)__shfl((int)lo[it], srcl), b_ = (uint32_t)__shfl((int)hi[it], srcl);
+            const uint32_t c_ = (uint32_t)__shfl((int)lo[it], srcl + 4), d_ = (uint32_t)__shfl((int)hi[it], srcl + 4);
+            if ((lane >> 3) == it) {
+                nj = a_;
+                s0 = b_;
+                s1 = c_;
+                s2 = d_;
             }
+        }
+        
             SEG_MARK(3)
             // centre update + stop rule (:93-107); lane j < k holds centre j and its previous value
             const unsigned long long empty = __ballot(lane < k && nj == 0);
             if (empty) {
-                if (DEDUP)
-                    resample_empty_listed(empty, pix, idx, L.sxy + run_at, n, xmin, ymin, xmax, ymax, W,
-                                          seed, cen, KM);
-                else
-                    resample_empty(empty, pix, pos, n, bw, xmin, ymin, W, seed, cen, KM);
+                resample_empty(empty, pix, pos, n, bw, xmin, ymin, W, seed, cen, KM);
             }
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             if (lane < k) {
@@ -1026,11 +856,7 @@ __device__ __forceinline__ bool segment_body(
             // centre update + stop rule (:93-107)
             const unsigned long long empty = __ballot(lane < k && red[(lane < k ? lane : 0) * 4] == 0u);
             if (empty) {
-                if (DEDUP)
-                    resample_empty_listed(empty, pix, idx, L.sxy + run_at, n, xmin, ymin, xmax, ymax, W,
-                                          seed, cen, KM);
-                else
-                    resample_empty(empty, pix, pos, n, bw, xmin, ymin, W, seed, cen, KM);
+                resample_empty(empty, pix, pos, n, bw, xmin, ymin, W, seed, cen, KM);
             }
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
             if (lane < k) {
@@ -1098,19 +924,7 @@ __device__ __forceinline__ bool segment_body(
     for (int i = tid; i < k * 3 * 64; i += THREADS) acc[i] = 0;
     __syncthreads();
     const float inv_bw = 1.0f / (float)bw;
-    if (DEDUP) {
-        // squares per distinct colour, weighted (a lane's sums stay below n * 255^2 < 2^32) ...
-        for (int i = tid; i < nloop; i += THREADS) {
-            const uint32_t v = pix[i], weight = ucnt[i];
-            const uint32_t u0 = v & 255u, u1 = (v >> 8) & 255u, u2 = (v >> 16) & 255u, bi = v >> 24;
-            atomicAdd(&acc[(bi * 3) * 64 + lane], weight * (u0 * u0));
-            atomicAdd(&acc[(bi * 3 + 1) * 64 + lane], weight * (u1 * u1));
-            atomicAdd(&acc[(bi * 3 + 2) * 64 + lane], weight * (u2 * u2));
-        }
-        // ... the assignment goes back to the image further down, once the positions have been
-        // read from the list again (one batch of loads for both uses)
-    }
-    for (int i = tid; i < (DEDUP ? 0 : n); i += THREADS) {
+    for (int i = tid; i < n; i += THREADS) {
         const uint32_t v = pix[i];
         const uint32_t u0 = v & 255u, u1 = (v >> 8) & 255u, u2 = (v >> 16) & 255u, bi = v >> 24;
         atomicAdd(&acc[(bi * 3) * 64 + lane], u0 * u0);
@@ -1156,31 +970,8 @@ __device__ __forceinline__ bool segment_body(
 #pragma unroll
     for (int t = 0; t < NPT; ++t) {
         const int i = tid + t * THREADS;
-        if (DEDUP) {
-            // box offset from the list's position (clamped into the box as when the run was loaded)
-            keep[t] = 0xffffffffu;
-            if (i < n) {
-                const uint32_t xy = L.sxy[run_at + i];
-                const int x = min(max((int)(xy & 0xffffu), xmin), xmax);
-                const int y = min(max((int)(xy >> 16), ymin), ymax);
-                keep[t] = (uint32_t)(__mul24(y - ymin, bw) + (x - xmin)) | ((pix[idx[i]] >> 24) << 16);
-            }
-        } else {
-            keep[t] = i < n ? ((uint32_t)pos[i] | ((pix[i] >> 24) << 16)) : 0xffffffffu;
-        }
-    }
-    if (DEDUP) {
-        // assignment back to the image
-#pragma unroll
-        for (int t = 0; t < NPT; ++t)
-            if (keep[t] != 0xffffffffu) {
-                const int o = (int)(keep[t] & 0xffffu);
-                int yy = (int)((float)o * inv_bw);
-                int xx = o - __mul24(yy, bw);
-                yy += (xx >= bw) - (xx < 0);
-                xx = o - __mul24(yy, bw);
-                if (assign) assign[img + (size_t)(uint32_t)(__mul24(ymin + yy, W) + xmin + xx)] = (uint8_t)(keep[t] >> 16);
-            }
+        keep[t] = i < n ? ((uint32_t)pos[i] | ((pix[i] >> 24) << 16)) : 0xffffffffu;
+    
     }
     uint16_t* par = reinterpret_cast<uint16_t*>(smem);
     uint8_t* cls = smem;
@@ -1305,24 +1096,23 @@ __device__ __forceinline__ bool segment_body(
         st.rounds = s_done;
         seg[gs] = st;
     }
-    return true;
 }
 
 // LDS of one workgroup: the layout at the top of segment_body; the last 16 bytes are its flags
 // (s_n, s_done) and the ticket of the listed mode
-__host__ __device__ constexpr size_t seg_lds_bytes(int km, int cap, bool dedup = false) {
-    return (size_t)cap * 6 + (size_t)km * (!dedup && (cap / 64) * 255 < 65536 ? 3 : 4) * 64 * 4 +
+__host__ __device__ constexpr size_t seg_lds_bytes(int km, int cap) {
+    return (size_t)cap * 6 + (size_t)km * ((cap / 64) * 255 < 65536 ? 3 : 4) * 64 * 4 +
            (size_t)km * 8 + (size_t)km * 3 * 4 * 2 + (size_t)km * 4 * 4 + (size_t)km * 3 * 4 + 16;
 }
 
 // waves per SIMD when as many workgroups as the LDS allows share a CU: the register budget the
 // compiler is held to (the listed mode's body otherwise settles above it, and a workgroup fewer fits)
-constexpr int seg_waves_per_simd(int km, int cap, int threads, bool dedup) {
-    return (threads / 256) * (int)((160 * 1024) / seg_lds_bytes(km, cap, dedup));
+constexpr int seg_waves_per_simd(int km, int cap, int threads) {
+    return (threads / 256) * (int)((160 * 1024) / seg_lds_bytes(km, cap));
 }
 
 template <int KM, int CAP, int THREADS, int MODE>
-__global__ __launch_bounds__(THREADS, seg_waves_per_simd(KM, CAP, THREADS, MODE == MODE_DEDUP))
+__global__ __launch_bounds__(THREADS, seg_waves_per_simd(KM, CAP, THREADS))
 void dcd_segment_kernel(
     const uint8_t* __restrict__ lab, const int32_t* __restrict__ labels, int B, int H, int W,
     int nseg, int k, int use_hash, uint32_t seed, float* __restrict__ centres,
@@ -1334,10 +1124,10 @@ void dcd_segment_kernel(
         segment_body<KM, CAP, THREADS, MODE_FIRST>(smem, blockIdx.y, blockIdx.x, B, lab, labels, H, W,
                                                    nseg, k, use_hash, seed, centres, assign, seg,
                                                    stats, bbox, retry, big_count, max_rounds, L, 0);
-    } else if (MODE == MODE_LISTED || MODE == MODE_DEDUP) {
+    } else if (MODE == MODE_LISTED) {
         // the workgroups draw tickets for the entries of their list: segments differ in size and
         // in rounds by an order of magnitude, so a fixed split would leave a long tail
-        int* ticket = reinterpret_cast<int*>(smem + seg_lds_bytes(KM, CAP, MODE == MODE_DEDUP) - 8);
+        int* ticket = reinterpret_cast<int*>(smem + seg_lds_bytes(KM, CAP) - 8);
         const int count = L.hdr[tier];
         while (true) {
             if (threadIdx.x == 0) *ticket = atomicAdd(&L.hdr[8 + tier], 1);
@@ -1346,17 +1136,9 @@ void dcd_segment_kernel(
             __syncthreads();
             if (e >= count) break;
             const int gs = L.tier[tier][e];
-            // MODE_DEDUP: a segment whose colours do not fit the table runs the plain body in the
-            // same workgroup (its LDS layout is the smaller one)
-            if (!segment_body<KM, CAP, THREADS, MODE>(smem, gs / nseg, gs % nseg, B, lab, labels, H, W, nseg,
-                                                      k, use_hash, seed, centres, assign, seg, stats, bbox,
-                                                      retry, big_count, max_rounds, L, tier)) {
-                __syncthreads();
-                segment_body<KM, CAP, THREADS, MODE_LISTED>(smem, gs / nseg, gs % nseg, B, lab, labels, H, W,
-                                                            nseg, k, use_hash, seed, centres, assign, seg,
-                                                            stats, bbox, retry, big_count, max_rounds, L,
-                                                            tier);
-            }
+            segment_body<KM, CAP, THREADS, MODE_LISTED>(smem, gs / nseg, gs % nseg, B, lab, labels, H, W, nseg,
+                                                        k, use_hash, seed, centres, assign, seg, stats, bbox,
+                                                        retry, big_count, max_rounds, L, tier);
             __syncthreads();
         }
     } else {
@@ -1379,7 +1161,7 @@ int launch_tier(dim3 grid, hipStream_t st, const uint8_t* lab, const int32_t* la
                 int W, int nseg, int k, int use_hash, uint32_t seed, float* centres, uint8_t* assign,
                 SegState* seg, unsigned long long* stats, const int* bbox, int* retry, int* n_big,
                 int max_rounds, const SegLists& L, int tier) {
-    size_t lds = seg_lds_bytes(KM, CAP, MODE == MODE_DEDUP);
+    size_t lds = seg_lds_bytes(KM, CAP);
     auto fn = dcd_segment_kernel<KM, CAP, THREADS, MODE>;
     IMGAN_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
@@ -1517,12 +1299,7 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
     hipLaunchKernelGGL(seg_scatter_kernel<false>, gsc, dim3(256), 0, st, lab, labels, B, H, W, nseg, L,
                        (int32_t*)nullptr);
     unsigned long long* stt = (unsigned long long*)stats;
-    // IMGAN_DCD_TIERS=old: the round-2 dedup kernels of this file (for comparisons)
-    static const bool new_tiers = [] {
-        const char* e = getenv("IMGAN_DCD_TIERS");
-        return !(e && e[0] == 'o');
-    }();
-    if (dedup && new_tiers) {
+    if (dedup) {
         // the dedup tiers (dcd_tiers.hip), smallest first; what overflows every colour table ends
         // up on list 3 and takes the plain body here, one workgroup per CU
         if (int rc = imgan_dcd_launch_dedup_tiers(lab, B, H, W, nseg, k, use_hash_init, seed, centres,
@@ -1542,6 +1319,7 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
         }
         return imgan::check_launch("imgan_dcd_segments_listed");
     }
+    // IMGAN_DCD_DEDUP=0: every segment through the plain body, the tiers as the plan made them.
     // The large tier first (its few long jobs should not be what everything else waits for at the
     // end); a grid of a few workgroups per CU slot, which draw segments until the tier's list is
     // empty.  (Measured: the tiers on three streams side by side gain 2 % at 64 images and lose
@@ -1552,17 +1330,10 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
             use_hash_init, seed, centres, assign, seg, stt, bbox, nullptr, n_big_out, max_rounds, L,  \
             T))                                                                                       \
         return rc;
-    if (k <= 8 && dedup) {
-        TIER(8, CAP_LARGE, THREADS_LARGE, MODE_DEDUP, 1, 2)
-        TIER(8, CAP_SMALL_D, THREADS_SMALL, MODE_DEDUP, 2, 1)
-        TIER(8, CAP_TINY_D, THREADS_TINY, MODE_DEDUP, 3, 0)
-    } else if (k <= 8) {
+    if (k <= 8) {
         TIER(8, CAP_LARGE, THREADS_LARGE, MODE_LISTED, 1, 2)
         TIER(8, CAP_SMALL_D, THREADS_SMALL, MODE_LISTED, 2, 1)
         TIER(8, CAP_TINY_D, THREADS_TINY, MODE_LISTED, 3, 0)
-    } else if (dedup) {
-        TIER(16, CAP_LARGE, THREADS_LARGE, MODE_DEDUP, 1, 2)
-        TIER(16, CAP_SMALL_K16, THREADS_SMALL, MODE_DEDUP, 2, 1)
     } else {
         TIER(16, CAP_LARGE, THREADS_LARGE, MODE_LISTED, 1, 2)
         TIER(16, CAP_SMALL_K16, THREADS_SMALL, MODE_LISTED, 2, 1)

@@ -24,6 +24,11 @@
 //     whose colours overflow the table is put on the next tier's list (larger table) -- the last
 //     tier hands it to the plain body of dcd_seg.hip, launched after the tiers.
 //   * the assignment map is optional (the batch pipeline does not read it).
+// Tried and left out: thread 0 fetching the workgroup's next ticket, list entry, run and box while
+// the current segment is worked on (three round trips to global memory off the critical path).  The
+// build with it hung in the test suite: nine more values alive across the whole body under a
+// one-lane branch, on top of ~400 scalar-register spills, is the situation DESIGN.md's "fragility"
+// note describes; the chain costs about 3 % of a segment.
 //
 // Arithmetic is the reference's, as in dcd_seg.hip: float32 distance sqrt((d0^2+d1^2)+d2^2) with a
 // strict '<' (evaluated literally only when two squared distances are within 2^-15 of each other),
@@ -179,6 +184,10 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
                 uint32_t slot = __umulhi(hc, (uint32_t)TH);
                 const uint32_t step = 1u + (hc & 62u);     // odd steps < 64 << TH
                 int probe = 0;
+                // NOT unrolled: as 64 nested one-lane branches this loop was 6,000 lines of code and the
+                // source of nearly all of the 400 scalar-register spills the kernel once had (it ran
+                // 2 % faster that way; partly unrolled, by 8, it is 5 % slower than either)
+#pragma unroll 1
                 for (; probe < DEDUP_PROBES; ++probe) {
                     const uint32_t seen = atomicCAS(&tab[slot], NO_COLOUR, c);
                     if (seen == NO_COLOUR || seen == c) break;
@@ -487,7 +496,6 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     // positions come from the list again --; the table's place is then reused as a grid over the
     // box: first the cluster of every cell (u8), from which each cell picks its link (kept in its
     // register as a direction), then, in the same place, the parents (u16).
-    const float inv_bw = 1.0f / (float)bw;
     uint32_t keep[NPT];
 #pragma unroll
     for (int t = 0; t < NPT; ++t) {
@@ -498,7 +506,10 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             const int x = min(max((int)(xy & 0xffffu), xmin), xmax);
             const int y = min(max((int)(xy >> 16), ymin), ymax);
             const uint32_t cl = tab[idx[i]] >> 24;
-            keep[t] = (uint32_t)(__mul24(y - ymin, bw) + (x - xmin)) | (cl << 16);
+            // bits 29-31: the cell has a row above / a column to its left / to its right in the box
+            const uint32_t edges = (y > ymin ? 0x20000000u : 0u) | (x > xmin ? 0x40000000u : 0u) |
+                                   (x < xmax ? 0x80000000u : 0u);
+            keep[t] = (uint32_t)(__mul24(y - ymin, bw) + (x - xmin)) | (cl << 16) | edges;
             if (A.assign) A.assign[img + (size_t)(uint32_t)(__mul24(y, W) + x)] = (uint8_t)cl;
         }
     }
@@ -514,10 +525,12 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     constexpr int JOINS = 2 * BUF * 2;
     if (tid == 0) s_joins = 0;
     __syncthreads();
+    TIER_MARK(9)
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
         if (keep[t] != 0xffffffffu) cls[keep[t] & 0xffffu] = (uint8_t)(keep[t] >> 16);
     __syncthreads();
+    TIER_MARK(10)
     // Every cell hangs itself under one earlier neighbour of its cluster (N, else W, else NW, else
     // NE; all have a smaller index, so the links form a forest) with a plain store.  Of the four
     // backward links only one more can be needed: with N present the others follow from the
@@ -530,11 +543,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
         if (keep[t] != 0xffffffffu) {
             const uint32_t cell = keep[t] & 0xffffu;
             const uint8_t c = (uint8_t)(keep[t] >> 16);
-            int yy = (int)((float)cell * inv_bw);
-            int xx = (int)cell - __mul24(yy, bw);
-            yy += (xx >= bw) - (xx < 0);
-            xx = (int)cell - __mul24(yy, bw);
-            const bool up = yy > 0, lf = xx > 0, rt = xx < bw - 1;
+            const bool up = (keep[t] >> 29) & 1u, lf = (keep[t] >> 30) & 1u, rt = keep[t] >> 31;
             const bool n_ = up && cls[cell - bw] == c, w_ = lf && cls[cell - 1] == c;
             const bool nw = up && lf && cls[cell - bw - 1] == c;
             const bool ne = up && rt && cls[cell - bw + 1] == c;
@@ -551,6 +560,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
         }
     }
     __syncthreads();                                       // every cluster byte has been read
+    TIER_MARK(11)
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
         if (keep[t] != 0xffffffffu) {
@@ -560,6 +570,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             par[cell] = (uint16_t)link;
         }
     __syncthreads();
+    TIER_MARK(12)
     for (int e = tid, ne_ = min(s_joins, JOINS); e < ne_; e += THREADS) {
         const uint32_t cell = joins[e];
         unite16(par, cell, cell - bw + 1);
@@ -573,6 +584,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             }
     }
     __syncthreads();
+    TIER_MARK(13)
     // roots into registers (bit 24: this cell is a root), then the parent grid turns into 16-bit
     // size counters (two per word; a segment has < 65536 pixels, so no carry)
 #pragma unroll
@@ -584,8 +596,10 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             keep[t] = root | (keep[t] & 0xff0000u) | (root == cell ? 0x1000000u : 0u);
         }
     __syncthreads();
+    TIER_MARK(14)
     for (int i = tid; i < (area + 1) / 2; i += THREADS) reinterpret_cast<uint32_t*>(par)[i] = 0;
     __syncthreads();
+    TIER_MARK(15)
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
         if (keep[t] != 0xffffffffu) {
@@ -593,12 +607,13 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             atomicAdd(reinterpret_cast<uint32_t*>(par) + (root >> 1), 1u << ((root & 1u) * 16u));
         }
     __syncthreads();
+    TIER_MARK(16)
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
         if (keep[t] != 0xffffffffu && (keep[t] & 0x1000000u))
             atomicMax(&largest[(keep[t] >> 16) & 0xffu], (uint32_t)par[keep[t] & 0xffffu]);
     __syncthreads();
-    TIER_MARK(8)
+    TIER_MARK(17)
     if (tid < k) out[tid * 8 + 7] = largest[tid];
     if (tid == 0) {
         st.rounds = rounds;

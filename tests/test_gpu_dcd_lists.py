@@ -70,10 +70,10 @@ def test_slic_label_counts_are_the_counts_of_the_label_map():
         assert np.array_equal(plan.label_counts().cpu().numpy()[0], want), it
 
 
-@pytest.mark.parametrize("k", [3, 8, 12])
+@pytest.mark.parametrize("k", [3, 5, 8, 12])
 def test_listed_equals_gather_on_superpixels(k):
-    """SLIC superpixels of two images (all three tiers for k <= 8 -- 7,168 / 11,520 / 22,528 px, in
-    dedup mode -- and the two plain tiers for k = 12), hash-sampled initial centres."""
+    """SLIC superpixels of two images (all three dedup tiers for k <= 8 -- 7,168 / 11,520 / 22,528
+    px -- and the two for k = 12), hash-sampled initial centres."""
     torch = _torch()
     from imgan import ops
     from oracle.color import bgr2lab_u8
@@ -298,3 +298,34 @@ def test_step_outputs_do_not_depend_on_the_run():
         else:
             for a, b in zip(ref, got):
                 assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("k", [3, 8])
+def test_listed_equals_gather_on_a_bench_sized_batch(k):
+    """The check that caught the round-2 builds that came out wrong (tools/check_lists_vs_gather.py),
+    as a collected test: 8 bench images (1080p, K = 400: 2,912 superpixels, every tier), the dedup
+    tiers against the box gather and against a second run of themselves, every segment's centres,
+    statistics, round counts and assignment bit for bit."""
+    torch = _torch()
+    from bench import synth_batch
+    from imgan import ops
+    B, H, W, K = 8, 1080, 1920, 400
+    lab = ops.bgr2lab(synth_batch(B, H, W, K, 4242, "cuda"))
+    slic = ops.SlicPlan(B, H, W, K)
+    slic.run(lab, 15, 10)
+    dl = slic.labels
+
+    def run(lists):
+        plan = ops.DcdPlan(B, H, W, slic.n, k, lists=lists)
+        cen = torch.zeros((B, slic.n, k, 3), dtype=torch.float32, device="cuda")
+        plan.kmeans(lab, dl, cen, seed=99 + k)
+        stats = plan.statistics(lab, dl)
+        rounds, _ = plan.rounds()
+        return cen.view(torch.int32).clone(), stats.clone(), rounds.clone(), plan.assign.clone(), plan.big_segments
+
+    gather, lists, again = run(False), run(True), run(True)
+    for x, y in ((gather, lists), (lists, again)):
+        assert x[4] == y[4] == 0
+        differ = ((x[0] != y[0]).flatten(2).any(2) | (x[1] != y[1]).flatten(2).any(2) | (x[2] != y[2]))
+        assert int(differ.sum()) == 0, int(differ.sum())
+        assert torch.equal(x[3], y[3])

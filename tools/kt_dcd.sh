@@ -1,11 +1,11 @@
-# per-kernel durations of the dominant-colour stage, old (IMGAN_DCD_TIERS=old) and new tiers (GPU box)
-# usage: bash tools/kt_dcd.sh <B> <outdir under gpurun_out> [variants: old new or exp tags]
+# per-kernel durations of the dominant-colour stage: the product library ("new") or experiment builds (GPU box)
+# usage: bash tools/kt_dcd.sh <B> <outdir under gpurun_out> [variants: new, or tags of imgan/exp/<tag>.so]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B=${1:-256}; OUT=gpurun_out/${2:-ktd}; shift 2
 mkdir -p $OUT
-for v in ${*:-old new}; do
-  unset IMGAN_LIB IMGAN_DCD_TIERS
-  if [ $v = old ]; then export IMGAN_DCD_TIERS=old; elif [ $v != new ]; then export IMGAN_LIB=$PWD/image-analysis_amd/imgan/exp/$v.so; fi
+for v in ${*:-new}; do
+  unset IMGAN_LIB
+  if [ $v != new ]; then export IMGAN_LIB=$PWD/image-analysis_amd/imgan/exp/$v.so; fi
   rm -rf $OUT/$v
   timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/$v -o k -- python3 tools/time_dcd.py $B $v > $OUT/$v.log 2>&1 || { tail -5 $OUT/$v.log; exit 1; }
   echo "== $v"; grep "dcd stage" $OUT/$v.log

@@ -20,7 +20,8 @@ pipe.run_dcd()
 torch.cuda.synchronize()
 lib.imgan_debug_tier_timing(buf, 1)
 names = ["init + clear", "load + table", "close-up", "assign", "barrier", "fold + update", "statistics",
-         "positions + assign out", "coherence"]
+         "positions + assign out", "-", "cc: clear grid", "cc: cluster bytes", "cc: links + join list",
+         "cc: parents", "cc: unions", "cc: roots", "cc: clear counters", "cc: count", "cc: largest"]
 nseg = buf[31]
 tot = sum(buf[:len(names)])
 for n, v in zip(names, buf):
