@@ -396,17 +396,24 @@ constexpr int CS_W = 32, CS_H = 16, CS_PW = CS_W + 7, CS_PH = CS_H + 7;
 
 // one thread per window origin on the sub-sampled grid, two rows of origins per thread; 32 x 16
 // windows per workgroup (a patch of 39 x 23 cells: 1.75 cells quantised per window, 2.3 with 8 rows)
+// labels != NULL: the colour structure of ONE region over its bounding box (origin x0, y0 in an
+// image of width W; cells of other regions hold no colour, out[nbins] counts the windows that hold
+// a cell of the region) -- the form imgan_region_descriptors_large launches with one image.
 __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ img, int H, int W,
                                                   int K, int nwx, int nwy, int nbins,
-                                                  int32_t* __restrict__ out, HmmdTab T) {
+                                                  int32_t* __restrict__ out, HmmdTab T,
+                                                  const int32_t* __restrict__ labels, int region,
+                                                  int x0, int y0) {
     __shared__ uint32_t runs[CS_PH * 8 * CS_W];     // [patch row][mask word][column]
     __shared__ uint32_t hist[256];
+    __shared__ uint32_t held;                       // windows that hold a cell of the region
     __shared__ float rcp2d[256];
     __shared__ int4 sub8[5 * 2];
     const int b = blockIdx.z;
     const int u0 = blockIdx.x * CS_W, v0 = blockIdx.y * CS_H;
     const uint8_t* im = img + (size_t)b * H * W * 3;
     for (int i = threadIdx.x; i < 256; i += 256) hist[i] = 0;
+    if (threadIdx.x == 0) held = 0;
     for (int i = threadIdx.x; i < CS_PH * 8 * CS_W / 4; i += 256)
         reinterpret_cast<uint4*>(runs)[i] = make_uint4(0, 0, 0, 0);
     rcp2d[threadIdx.x] = 1.0f / (float)(2 * max((int)threadIdx.x, 1));
@@ -425,11 +432,14 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
         int pv = i / CS_PW, pu = i - pv * CS_PW;
         int u = u0 + pu, v = v0 + pv;
         uint32_t c = 0;
+        bool has = true;                            // a cell past the last window: colour 0, never read
         if (u < nwx + 7 && v < nwy + 7) {
-            const uint8_t* q = im + ((size_t)(v * K) * W + (size_t)u * K) * 3;
+            const size_t p = (size_t)(y0 + v * K) * W + (size_t)(x0 + u * K);
+            const uint8_t* q = im + p * 3;
             c = (uint32_t)hmmd_cell_tab(q[0], q[1], q[2], T, rcp2d, sub8);
+            if (labels) has = labels[p] == region;
         }
-        const uint32_t bit = 1u << (c & 31u);
+        const uint32_t bit = has ? 1u << (c & 31u) : 0u;
         uint32_t* row = runs + (pv * 8 + (int)(c >> 5)) * CS_W;
 #pragma unroll
         for (int du = 0; du < 8; ++du)
@@ -447,6 +457,10 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
 #pragma unroll
                 for (int w = 0; w < 8; ++w) m[w] |= runs[((tv + dv) * 8 + w) * CS_W + tu];
         }
+        if (labels) {
+            const unsigned long long some = __ballot(((m[0] | m[1]) | (m[2] | m[3])) | ((m[4] | m[5]) | (m[6] | m[7])));
+            if (lane == 0 && some) atomicAdd(&held, (uint32_t)__popcll(some));
+        }
         // every colour present in a window counts once: count lanes per bit, one add per wave
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
@@ -463,7 +477,102 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
     int32_t* o = out + (size_t)b * (nbins + 1);
     for (int i = threadIdx.x; i < nbins; i += 256)
         if (hist[i]) atomicAdd(&o[i], (int32_t)hist[i]);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) o[nbins] = nwx * nwy;
+    if (labels) {
+        if (threadIdx.x == 0 && held) atomicAdd(&o[nbins], (int32_t)held);
+    } else if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        o[nbins] = nwx * nwy;
+    }
+}
+
+// ---- regions beyond the on-chip capacity of region_desc_kernel (merged regions of the class API:
+// a box of up to the whole frame), one region per call, streaming with global atomics.  Colour
+// layout sums and the edge histogram's quadrant sums in one pass over the box: a thread owns a
+// column of the box and walks down LG_ROWS rows, so its grid column, edge block column and
+// quadrant half are fixed and its sums stay in registers while the grid row / block row / quadrant
+// half do not change.
+constexpr int LG_ROWS = 32;
+
+// lg: u64 [64][4] colour layout sums, then u32 [nblk][5] = four quadrant grey sums + member count
+__global__ __launch_bounds__(256) void region_large_sums_kernel(
+    const uint8_t* __restrict__ im, const int32_t* __restrict__ lab, int W, int region, int x0, int y0,
+    int bw, int bh, int bs, int nbx, int nby, unsigned long long* __restrict__ cld, uint32_t* __restrict__ q5) {
+    const int tid = threadIdx.x;
+    const int xx = blockIdx.x * 256 + tid, ya = blockIdx.y * LG_ROWS, yb = min(ya + LG_ROWS, bh);
+    if (xx < bw) {
+        const int gx = (int)(((long long)xx * 8) / bw);
+        const int hb = bs >> 1;
+        const bool inblk = xx < nbx * bs;
+        const int bx = inblk ? xx / bs : 0;
+        const int qx = inblk && (xx - bx * bs) >= hb ? 1 : 0;
+        uint32_t sb = 0, sg = 0, sr = 0, sn = 0;        // colour layout: this column, current grid row
+        int gy_cur = (int)(((long long)ya * 8) / bh);
+        uint32_t eg = 0, en = 0;                        // edge histogram: current (block row, half)
+        int by_cur = -1, qy_cur = 0;
+        auto flush_cld = [&]() {
+            if (sn) {
+                unsigned long long* d = cld + (size_t)(gy_cur * 8 + gx) * 4;
+                atomicAdd(&d[0], (unsigned long long)sb);
+                atomicAdd(&d[1], (unsigned long long)sg);
+                atomicAdd(&d[2], (unsigned long long)sr);
+                atomicAdd(&d[3], (unsigned long long)sn);
+            }
+            sb = sg = sr = sn = 0;
+        };
+        auto flush_ehd = [&]() {
+            if (by_cur >= 0) {
+                uint32_t* d = q5 + (size_t)(by_cur * nbx + bx) * 5;
+                atomicAdd(&d[qy_cur * 2 + qx], eg);
+                if (en) atomicAdd(&d[4], en);
+            }
+            eg = en = 0;
+        };
+        for (int yy = ya; yy < yb; ++yy) {
+            const size_t p = (size_t)(y0 + yy) * W + (size_t)(x0 + xx);
+            const uint8_t* q = im + p * 3;
+            const uint32_t cb = q[0], cg = q[1], cr = q[2];
+            const bool mem = lab[p] == region;
+            const int gy = (int)(((long long)yy * 8) / bh);
+            if (gy != gy_cur) {
+                flush_cld();
+                gy_cur = gy;
+            }
+            if (mem) sb += cb, sg += cg, sr += cr, sn += 1;
+            if (inblk && yy < nby * bs) {
+                const int by = yy / bs, qy = (yy - by * bs) >= hb ? 1 : 0;
+                if (by != by_cur || qy != qy_cur) {
+                    flush_ehd();
+                    by_cur = by, qy_cur = qy;
+                }
+                eg += gray_px(cb, cg, cr);              // all pixels of the block; it votes only if
+                en += mem ? 1u : 0u;                    // the region holds every one of them
+            }
+        }
+        flush_cld();
+        flush_ehd();
+    }
+}
+
+// blocks that the region fills vote (oracle/mpeg7_std.py region_edge_histogram_counts)
+__global__ void region_large_ehd_kernel(const uint32_t* __restrict__ q5, int bw, int bh, int bs, int nbx,
+                                        int nby, int threshold, int32_t* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nbx * nby) return;
+    const uint32_t* q = q5 + (size_t)k * 5;
+    if (q[4] != (uint32_t)(bs * bs)) return;
+    const int by = k / nbx, bx = k - by * nbx;
+    const long long s1 = q[0], s2 = q[1], s3 = q[2], s4 = q[3];
+    const long long hbq = (long long)(bs / 2) * (bs / 2);
+    const long long v = s1 - s2 + s3 - s4, h = s1 + s2 - s3 - s4, d45 = s1 - s4, d135 = s2 - s3,
+                    nd = s1 - s2 - s3 + s4;
+    const long long e[5] = {v * v, h * h, 2 * d45 * d45, 2 * d135 * d135, 4 * nd * nd};
+    long long best = e[0];
+    int type = 0;
+    for (int i = 1; i < 5; ++i)
+        if (e[i] > best) best = e[i], type = i;
+    const int sub = (int)(((long long)bx * bs * 4) / bw) + (int)(((long long)by * bs * 4) / bh) * 4;
+    atomicAdd(&out[80 + sub], 1);
+    const long long thr = (long long)threshold * hbq;
+    if (best >= thr * thr) atomicAdd(&out[sub * 5 + type], 1);
 }
 
 // ------------------------------------------------------------------------------ per region
@@ -989,7 +1098,8 @@ extern "C" int imgan_csd(const uint8_t* bgr, int B, int H, int W, int nbins, int
     IMGAN_HIP(hipMemsetAsync(csd_out, 0, (size_t)B * (nbins + 1) * 4, st));
     if (nwx == 0 || nwy == 0) return 0;
     dim3 grid((unsigned)imgan::cdiv(nwx, CS_W), (unsigned)imgan::cdiv(nwy, CS_H), (unsigned)B);
-    hipLaunchKernelGGL(csd_kernel, grid, dim3(256), 0, st, bgr, H, W, K, nwx, nwy, nbins, csd_out, T);
+    hipLaunchKernelGGL(csd_kernel, grid, dim3(256), 0, st, bgr, H, W, K, nwx, nwy, nbins, csd_out, T,
+                       (const int32_t*)nullptr, 0, 0, 0);
     return imgan::check_launch("imgan_csd");
 }
 
@@ -1035,4 +1145,67 @@ extern "C" int imgan_region_descriptors(const uint8_t* bgr, const int32_t* label
     hipLaunchKernelGGL(cld_finalise_kernel, dim3(B * nseg * 3), dim3(64), 0, st,
                        (const unsigned long long*)scratch, B * nseg, cld_out, D, 1);
     return imgan::check_launch("imgan_region_descriptors");
+}
+
+static void make_dct(DctTable* D) {
+    for (int i = 0; i < 8; ++i) {
+        double sc = i == 0 ? sqrt(0.125) : 0.5;
+        for (int j = 0; j < 8; ++j) D->c[i * 8 + j] = sc * cos((M_PI / 8.0) * i * (j + 0.5));
+    }
+}
+
+// edge blocks of a box: (bw / bs)(bh / bs) with bs = 2 floor(sqrt(bw bh / 1100) / 2), at most 2:
+// about 1100 for large boxes, up to 4400 where the block size is held at 2
+constexpr size_t LG_MAX_BLOCKS = 4608;
+
+extern "C" size_t imgan_region_descriptors_large_scratch_bytes(int H, int W) {
+    if (H < 1 || W < 1) return 0;
+    return imgan::align_up(64 * 4 * 8 + LG_MAX_BLOCKS * 5 * 4, 256);
+}
+
+extern "C" int imgan_region_descriptors_large(const uint8_t* bgr, const int32_t* labels, int H, int W,
+                                              int region, int x0, int y0, int x1, int y1, int nbins,
+                                              int32_t* cld_out, int32_t* ehd_out, int32_t* csd_out,
+                                              void* scratch, imgan_stream_t stream) {
+    IMGAN_REQUIRE(bgr && labels && cld_out && ehd_out && csd_out && scratch,
+                  "imgan_region_descriptors_large: null pointer");
+    IMGAN_REQUIRE(H >= 1 && W >= 1 && W < (1 << 23) && H < (1 << 23),
+                  "imgan_region_descriptors_large: bad shape");
+    IMGAN_REQUIRE(0 <= x0 && x0 <= x1 && x1 < W && 0 <= y0 && y0 <= y1 && y1 < H,
+                  "imgan_region_descriptors_large: the box must lie inside the image");
+    HmmdTab T;
+    if (int rc = make_hmmd(nbins, &T)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+    const int bs = ehd_block_size(bh, bw), nbx = bw / bs, nby = bh / bs;
+    IMGAN_REQUIRE((double)(bs / 2) * (bs / 2) * 255.0 < 4294967295.0,
+                  "imgan_region_descriptors_large: box too large");
+    IMGAN_REQUIRE((size_t)nbx * nby <= LG_MAX_BLOCKS,
+                  "imgan_region_descriptors_large: more edge blocks than the scratch holds");
+    unsigned long long* cld = (unsigned long long*)scratch;
+    uint32_t* q5 = (uint32_t*)((char*)scratch + 64 * 4 * 8);
+    IMGAN_HIP(hipMemsetAsync(scratch, 0, 64 * 4 * 8 + (size_t)std::max(nbx * nby, 1) * 5 * 4, st));
+    IMGAN_HIP(hipMemsetAsync(ehd_out, 0, 96 * 4, st));
+    IMGAN_HIP(hipMemsetAsync(csd_out, 0, (size_t)(nbins + 1) * 4, st));
+    dim3 grid((unsigned)imgan::cdiv(bw, 256), (unsigned)imgan::cdiv(bh, LG_ROWS));
+    hipLaunchKernelGGL(region_large_sums_kernel, grid, dim3(256), 0, st, bgr, labels, W, region, x0, y0, bw,
+                       bh, bs, nbx, nby, cld, q5);
+    if (nbx > 0 && nby > 0)
+        hipLaunchKernelGGL(region_large_ehd_kernel, dim3((unsigned)imgan::cdiv(nbx * nby, 256)), dim3(256), 0,
+                           st, (const uint32_t*)q5, bw, bh, bs, nbx, nby, 11, ehd_out);
+    DctTable D;
+    make_dct(&D);
+    hipLaunchKernelGGL(cld_finalise_kernel, dim3(3), dim3(64), 0, st, (const unsigned long long*)cld, 1,
+                       cld_out, D, 1);
+    // colour structure: sub-sampling from the box (oracle: csd_subsample(bh, bw))
+    const int pw = (int)floor(0.5 * log2((double)bw * bh) - 8.0 + 0.5);
+    const int K = 1 << (pw > 0 ? pw : 0);
+    const int nwx = bw >= 8 * K ? (bw - 8 * K) / K + 1 : 0;
+    const int nwy = bh >= 8 * K ? (bh - 8 * K) / K + 1 : 0;
+    if (nwx > 0 && nwy > 0) {
+        dim3 gc((unsigned)imgan::cdiv(nwx, CS_W), (unsigned)imgan::cdiv(nwy, CS_H), 1u);
+        hipLaunchKernelGGL(csd_kernel, gc, dim3(256), 0, st, bgr, H, W, K, nwx, nwy, nbins, csd_out, T, labels,
+                           region, x0, y0);
+    }
+    return imgan::check_launch("imgan_region_descriptors_large");
 }

@@ -706,12 +706,16 @@ class RegionDescriptorPlan(object):
         self.ehd = torch.empty((self.B, self.nseg, 96), dtype=torch.int32, device=dev)
         self.csd = torch.empty((self.B, self.nseg, self.nbins + 1), dtype=torch.int32, device=dev)
         self.too_big = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.large_scratch = None
+        self._last = None
         self.scratch = torch.empty(max(lib.imgan_region_descriptors_scratch_bytes(self.B, self.nseg), 8),
                                    dtype=torch.uint8, device=dev)
 
-    def run(self, bgr, labels, bbox=None):
+    def run(self, bgr, labels, bbox=None, large=False):
         """bbox: device buffer holding int32 [B,nseg,4] (e.g. the one the last SLIC round wrote);
-        found with imgan_label_bbox when not given.  Returns (cld, ehd, csd) device tensors."""
+        found with imgan_label_bbox when not given.  large: also finish the regions whose box is
+        too large for the on-chip pass (finish_large(); synchronises).  Returns (cld, ehd, csd)
+        device tensors."""
         bgr = as_batch(_dev(bgr, torch.uint8, "bgr"))
         if labels.dim() == 2:
             labels = labels.unsqueeze(0)
@@ -726,7 +730,41 @@ class RegionDescriptorPlan(object):
                                            self.nseg, self.nbins, _ptr(self.cld), _ptr(self.ehd),
                                            _ptr(self.csd), _ptr(self.too_big), _ptr(self.scratch),
                                            _stream()))
+        self._last = (bgr, labels, bbox)
+        if large:
+            self.finish_large()
         return self.cld, self.ehd, self.csd
+
+    def finish_large(self):
+        """Regions whose box did not fit the on-chip pass (counted in self.too_big; their rows are
+        zero until now) through imgan_region_descriptors_large, one region per call.  Synchronises
+        once to read the counter, and once more for the boxes when it is not zero.  Returns the
+        number of regions done this way."""
+        n_big = int(self.too_big.item())
+        if n_big == 0 or getattr(self, "_last", None) is None:
+            return 0
+        bgr, labels, bbox = self._last
+        if isinstance(bbox, torch.Tensor) and bbox.dtype == torch.int32:
+            boxes = bbox.reshape(-1)[:self.B * self.nseg * 4].view(self.B, self.nseg, 4).cpu().numpy()
+        else:                                   # a byte buffer that starts with the boxes (DcdPlan.bbox)
+            boxes = bbox.view(torch.int32)[:self.B * self.nseg * 4].view(self.B, self.nseg, 4).cpu().numpy()
+        if self.large_scratch is None:
+            self.large_scratch = torch.empty(lib.imgan_region_descriptors_large_scratch_bytes(self.H, self.W),
+                                             dtype=torch.uint8, device=self.cld.device)
+        done = 0
+        for b in range(self.B):
+            for r in range(self.nseg):
+                x0, y0 = max(int(boxes[b, r, 0]), 0), max(int(boxes[b, r, 1]), 0)
+                x1, y1 = min(int(boxes[b, r, 2]), self.W - 1), min(int(boxes[b, r, 3]), self.H - 1)
+                if x1 < x0 or y1 < y0 or (x1 - x0 + 1) * (y1 - y0 + 1) <= self.MAX_BOX_CELLS:
+                    continue
+                check(lib.imgan_region_descriptors_large(
+                    _ptr(bgr[b]), _ptr(labels[b]), self.H, self.W, r, x0, y0, x1, y1, self.nbins,
+                    _ptr(self.cld[b, r]), _ptr(self.ehd[b, r]), _ptr(self.csd[b, r]),
+                    _ptr(self.large_scratch), _stream()))
+                done += 1
+        self.too_big.zero_()
+        return done
 
 
 def hmmd_quantise(bgr, nbins=256):

@@ -167,6 +167,46 @@ class MPEG7Descriptors(object):
             return [int(v) for v in hist], nwin
         return csd_quantise(hist, nwin)
 
+    # ---- the same three per segment (relative to the segment's bounding box, only its pixels
+    # count: oracle/mpeg7_std.py "per region"); boxes of any size, up to the whole frame
+    def _region_rows(self, nbins=256):
+        key = ("rows", nbins)
+        if getattr(self, "_region_cache", None) is None or self._region_cache[0] != key:
+            segs, label_map = self._segment_index_map()
+            H, W = self.image_rgb.shape[:2]
+            plan = ops.RegionDescriptorPlan(1, H, W, len(segs), nbins)
+            d_labels = torch.from_numpy(label_map).cuda().unsqueeze(0)
+            cld, ehd, csd = plan.run(self._dev_bgr.unsqueeze(0), d_labels, large=True)
+            self._region_cache = (key, segs, cld[0].cpu().numpy(), ehd[0].cpu().numpy(),
+                                  csd[0].cpu().numpy())
+        return self._region_cache[1:]
+
+    def mpeg7_region_colour_layout(self, num_y=6, num_c=3):
+        """{segment: num_y Y + num_c Cb + num_c Cr coefficients} over every segment's own box."""
+        segs, cld, _, _ = self._region_rows()
+        return {int(seg): [int(v) for v in np.concatenate([cld[i, 0, :num_y], cld[i, 1, :num_c],
+                                                            cld[i, 2, :num_c]])]
+                for i, seg in enumerate(segs)}
+
+    def mpeg7_region_edge_histogram(self, quantised=True):
+        """{segment: 80 bins} from the edge blocks that lie wholly inside the segment."""
+        segs, _, ehd, _ = self._region_rows()
+        out = {}
+        for i, seg in enumerate(segs):
+            counts, nblk = ehd[i, :80], ehd[i, 80:]
+            out[int(seg)] = ehd_quantise(counts, nblk) if quantised else \
+                ([int(v) for v in counts], [int(v) for v in nblk])
+        return out
+
+    def mpeg7_region_colour_structure(self, nbins=256, quantised=True):
+        """{segment: nbins values} from the 8 x 8 windows of the segment's box that hold its pixels."""
+        segs, _, _, csd = self._region_rows(nbins)
+        out = {}
+        for i, seg in enumerate(segs):
+            hist, nwin = csd[i, :nbins], int(csd[i, nbins])
+            out[int(seg)] = csd_quantise(hist, nwin) if quantised else ([int(v) for v in hist], nwin)
+        return out
+
     # ------------------------------------------------------------------ region shape (ART)
     @staticmethod
     def _polar_tables(height, width):

@@ -344,7 +344,8 @@ int imgan_hmmd_quantise(const uint8_t* bgr, uint8_t* out, int64_t npix, int nbin
  * imgan_slic_assign_accumulate_bbox leave them.  cld_out int32 [B][nseg][3][64], ehd_out int32
  * [B][nseg][96], csd_out int32 [B][nseg][nbins+1].  A region whose box has more than 24,576 cells
  * does not fit on chip: its rows are zeroed and it is counted in too_big_out (device int32); such
- * regions (merged regions, whole frames) take the whole-image entry points on their crop.
+ * regions (merged regions of the class API, up to the whole frame) go through
+ * imgan_region_descriptors_large, one region per call.
  * One image holds at most 2^32 / 3 pixels (32-bit offsets inside an image; larger: error).
  * scratch: imgan_region_descriptors_scratch_bytes(B, nseg) bytes. */
 size_t imgan_region_descriptors_scratch_bytes(int B, int nseg);
@@ -352,6 +353,21 @@ int imgan_region_descriptors(const uint8_t* bgr, const int32_t* labels, const in
                              int H, int W, int nseg, int nbins, int32_t* cld_out, int32_t* ehd_out,
                              int32_t* csd_out, int32_t* too_big_out, void* scratch,
                              imgan_stream_t stream);
+
+/* The same three descriptors of ONE region of ONE image whose bounding box is too large for the
+ * on-chip pass above (MPEG7Descriptors is built on the merged regions, optigen_utils.py:46-49, whose
+ * boxes reach the whole frame): streaming kernels over the box -- colour-layout block sums and the
+ * edge histogram's quadrant sums by run-aggregated global atomics, the colour structure by the
+ * whole-image kernel with the region as a mask (sub-sampling from the box's size).  Same
+ * definitions (oracle/mpeg7_std.py "per region"), same results.  bgr / labels point at the image
+ * (H x W x 3 u8) and its label map; region: the label; x0..y1: its bounding box, inclusive, inside
+ * the image (IMGAN_E_INVALID otherwise).  cld_out int32 [3][64], ehd_out int32 [96], csd_out int32
+ * [nbins+1].  scratch: imgan_region_descriptors_large_scratch_bytes(H, W) bytes. */
+size_t imgan_region_descriptors_large_scratch_bytes(int H, int W);
+int imgan_region_descriptors_large(const uint8_t* bgr, const int32_t* labels, int H, int W, int region,
+                                   int x0, int y0, int x1, int y1, int nbins, int32_t* cld_out,
+                                   int32_t* ehd_out, int32_t* csd_out, void* scratch,
+                                   imgan_stream_t stream);
 
 /* ---- spatial relations (spatialextract.py) ------------------------------------
  * imgan_label_bbox: bounding box of every label (cv2.boundingRect of the segment mask,

@@ -422,3 +422,62 @@ def test_large_cluster_centre_sums_integer_vs_float32():
         assert np.allclose(f[j, 0:3], mean, rtol=1e-4, atol=0), (j, f[j, 0:3], mean)
         assert np.allclose(f[j, 3:6], var, rtol=1e-4, atol=1e-3)
         assert np.isclose(f[j, 6], share, rtol=1e-6) and np.isclose(f[j, 7], coh, rtol=1e-6)
+
+
+def _check_regions_against_oracle(torch, img, labels, nseg, expect_large):
+    from imgan import ops
+    plan = ops.RegionDescriptorPlan(1, img.shape[0], img.shape[1], nseg)
+    cld, ehd, csd = plan.run(torch.from_numpy(img).cuda().unsqueeze(0),
+                             torch.from_numpy(labels).cuda().unsqueeze(0))
+    assert int(plan.too_big.item()) == expect_large
+    assert plan.finish_large() == expect_large and int(plan.too_big.item()) == 0
+    cld, ehd, csd = cld.cpu().numpy()[0], ehd.cpu().numpy()[0], csd.cpu().numpy()[0]
+    for r in range(nseg):
+        if not (labels == r).any():
+            assert not cld[r].any() and not ehd[r].any() and not csd[r].any()
+            continue
+        wc, we, ws = _region_oracle_rows(img, labels, r)
+        assert np.array_equal(cld[r], wc), r
+        assert np.array_equal(ehd[r], we), r
+        assert np.array_equal(csd[r], ws), r
+    return cld, ehd, csd
+
+
+def test_region_descriptors_of_merged_regions_golden(golden_dir):
+    """The regions MPEG7Descriptors is actually built on (optigen_utils.py:46-49): the merged map of
+    the golden road image, where two regions' boxes (53,120 and 28,710 cells) exceed the on-chip
+    pass and take imgan_region_descriptors_large; every region against oracle.mpeg7_std."""
+    import os
+    torch = _torch()
+    f = np.load(os.path.join(golden_dir, "road_320.npz"))
+    img, merged = f["bgr"], f["merged"].astype(np.int32)
+    _check_regions_against_oracle(torch, img, merged, int(merged.max()) + 1, expect_large=2)
+    # the class methods on the same map (float64 labels as the reference hands them over)
+    from mpeg7Descriptors import MPEG7Descriptors, ehd_quantise, csd_quantise
+    from oracle import mpeg7_std as M
+    mp = MPEG7Descriptors(merged.astype(np.float64), img)
+    layout, edges, structure = (mp.mpeg7_region_colour_layout(), mp.mpeg7_region_edge_histogram(),
+                                mp.mpeg7_region_colour_structure())
+    assert sorted(layout) == sorted(int(v) for v in np.unique(merged))
+    for r in layout:
+        wc, we, ws = _region_oracle_rows(img, merged, r)
+        assert layout[r] == [int(v) for v in np.concatenate([wc[0, :6], wc[1, :3], wc[2, :3]])]
+        assert edges[r] == ehd_quantise(we[:80], we[80:])
+        assert structure[r] == csd_quantise(ws[:256], int(ws[256]))
+
+
+def test_region_descriptors_large_boxes_with_subsampling():
+    """Boxes of 2^17 cells and more sub-sample the colour structure (factor 2 here), and their
+    edge blocks grow past 4 pixels: a frame-filling background with holes, a ring and a half
+    frame, all through the streaming path, against the oracle."""
+    torch = _torch()
+    H, W = 520, 760
+    img = voronoi_image(H, W, 60, seed=12, noise=18.0)
+    labels = np.zeros((H, W), dtype=np.int32)                   # 0: the whole frame minus the rest
+    yy, xx = np.mgrid[0:H, 0:W]
+    d = np.hypot(yy - 260, xx - 300)
+    labels[(d < 230) & (d >= 120)] = 1                          # ring, box 460 x 460 -> factor 2
+    labels[:, 600:] = 2                                         # strip, box 160 x 520 -> factor 1
+    labels[400:, :200] = 3                                      # 120 x 200: on chip
+    labels[5:9, 700:704] = -1                                   # unlabelled hole
+    _check_regions_against_oracle(torch, img, labels, 5, expect_large=3)
