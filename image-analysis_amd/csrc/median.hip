@@ -273,6 +273,39 @@ int launch_median(const uint8_t* src, uint8_t* dst, int B, int H, int W, hipStre
 
 }  // namespace
 
+// Any other odd size (cv2.medianBlur takes them all; rag_segmentation.py:10-11 passes its
+// median_blur argument on): one thread per pixel, an 8-step search for the largest value v with at
+// least k^2 / 2 + 1 window values >= v, the three channels side by side, the window read from the
+// image with the replicated border as clamped coordinates.  k^2 byte loads per step and channel:
+// a path for completeness, not for speed.
+__global__ __launch_bounds__(256) void median_any_kernel(const uint8_t* __restrict__ src,
+                                                         uint8_t* __restrict__ dst, int H, int W, int k) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t img = (size_t)blockIdx.z * H * W * 3;
+    const int r = k >> 1, need = (k * k) / 2 + 1;
+    int lo0 = 0, lo1 = 0, lo2 = 0;
+    for (int bit = 7; bit >= 0; --bit) {
+        const int t0 = lo0 | (1 << bit), t1 = lo1 | (1 << bit), t2 = lo2 | (1 << bit);
+        int c0 = 0, c1 = 0, c2 = 0;
+        for (int dy = -r; dy <= r; ++dy) {
+            const int yy = min(max(y + dy, 0), H - 1);
+            const uint8_t* row = src + img + (size_t)yy * W * 3;
+            for (int dx = -r; dx <= r; ++dx) {
+                const uint8_t* p = row + (size_t)min(max(x + dx, 0), W - 1) * 3;
+                c0 += p[0] >= t0;
+                c1 += p[1] >= t1;
+                c2 += p[2] >= t2;
+            }
+        }
+        lo0 = c0 >= need ? t0 : lo0;
+        lo1 = c1 >= need ? t1 : lo1;
+        lo2 = c2 >= need ? t2 : lo2;
+    }
+    uint8_t* o = dst + img + ((size_t)y * W + x) * 3;
+    o[0] = (uint8_t)lo0, o[1] = (uint8_t)lo1, o[2] = (uint8_t)lo2;
+}
+
 extern "C" int imgan_median_u8c3(const uint8_t* src, uint8_t* dst, int B, int H, int W, int ksize,
                                  imgan_stream_t stream) {
     IMGAN_REQUIRE(src && dst, "imgan_median_u8c3: null pointer");
@@ -285,10 +318,14 @@ extern "C" int imgan_median_u8c3(const uint8_t* src, uint8_t* dst, int B, int H,
         case 5: return launch_median<5>(src, dst, B, H, W, st);
         case 7: return launch_median<7>(src, dst, B, H, W, st);
         default:
-            return imgan::fail(imgan::E_INVALID,
-                               "imgan_median_u8c3: ksize must be 3, 5 or 7 (cv2.medianBlur takes any odd "
-                               "size; the reference pipeline uses 7)");
+            break;
     }
+    IMGAN_REQUIRE(ksize >= 1 && ksize <= 255 && (ksize & 1),
+                  "imgan_median_u8c3: ksize must be odd, 1 to 255 (cv2.medianBlur: odd and > 1)");
+    IMGAN_REQUIRE((long long)imgan::cdiv(H, 4) <= 65535, "imgan_median_u8c3: image too tall for this kernel size");
+    hipLaunchKernelGGL(median_any_kernel, dim3((unsigned)imgan::cdiv(W, 64), (unsigned)imgan::cdiv(H, 4), (unsigned)B),
+                       dim3(256), 0, st, src, dst, H, W, ksize);
+    return imgan::check_launch("median_any_kernel");
 }
 
 extern "C" int imgan_median7_u8c3(const uint8_t* src, uint8_t* dst, int B, int H, int W,

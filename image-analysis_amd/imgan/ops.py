@@ -71,7 +71,8 @@ def bgr2gray(bgr, out=None):
 
 
 def median_blur(bgr, ksize=7, out=None):
-    """cv2.medianBlur(bgr, ksize), ksize 3, 5 or 7 (rag_segmentation.py:11 uses 7)."""
+    """cv2.medianBlur(bgr, ksize): any odd size; 3, 5 and 7 (rag_segmentation.py:11 uses 7) take
+    the bit-sliced kernels, the others a plain search per pixel."""
     _require_gpu()
     img = as_batch(_dev(bgr, torch.uint8, "bgr"))
     if out is None:

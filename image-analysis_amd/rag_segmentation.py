@@ -32,9 +32,8 @@ class RAGSegmentation(object):
         # rag_segmentation.py:10-19
         if not isinstance(image, np.ndarray):
             raise ValueError("Image value is None. Probably not loaded correctly!")
-        if median_blur not in (3, 5, 7):
-            raise ValueError("median_blur must be 3, 5 or 7 (cv2.medianBlur takes any odd size; the "
-                             "reference pipeline uses 7)")
+        if not (isinstance(median_blur, (int, np.integer)) and median_blur > 1 and median_blur % 2 == 1):
+            raise ValueError("median_blur must be an odd size greater than 1 (cv2.medianBlur)")
         dev = torch.from_numpy(np.ascontiguousarray(image)).cuda()
         self._dev_image = ops.median_blur(dev, median_blur)       # cv2.medianBlur(image, median_blur)
         self._dev_lab = ops.bgr2lab(self._dev_image)

@@ -51,7 +51,8 @@ int imgan_bgr2gray_u8(const uint8_t* bgr, uint8_t* gray, int64_t npix, imgan_str
 int imgan_median7_u8c3(const uint8_t* src, uint8_t* dst, int B, int H, int W,
                        imgan_stream_t stream);
 /* cv2.medianBlur(image, ksize) for the other kernel sizes RAGSegmentation's median_blur argument
- * may carry (rag_segmentation.py:10-11): ksize = 3, 5 or 7. */
+ * may carry (rag_segmentation.py:10-11): any odd ksize from 1 to 255 (3, 5 and 7 take the
+ * bit-sliced kernels, the rest a plain per-pixel search; IMGAN_E_INVALID for an even size). */
 int imgan_median_u8c3(const uint8_t* src, uint8_t* dst, int B, int H, int W, int ksize,
                       imgan_stream_t stream);
 

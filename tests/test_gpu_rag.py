@@ -42,13 +42,30 @@ def test_median_sizes_tiles_and_borders(ksize, shape):
         assert np.array_equal(got[b], median_blur(imgs[b], ksize)), (b, ksize, shape)
 
 
-def test_median_rejects_other_sizes():
+def test_median_other_odd_sizes_and_rejections():
+    """cv2.medianBlur takes any odd size: 9, 11 and 15 go through the plain per-pixel search (1 is
+    the identity for the C entry point); even sizes are refused, and RAGSegmentation refuses what
+    cv2 refuses (even, or not greater than 1)."""
     torch = _torch()
     from imgan import ops
-    img = torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda")
-    for ksize in (1, 4, 9):
+    from oracle.color import median_blur
+    from rag_segmentation import RAGSegmentation
+    rng = np.random.RandomState(11)
+    img = np.stack([rng.randint(0, 256, (37, 53, 3)), (rng.randint(0, 256, (37, 53, 3)) // 64) * 64]).astype(np.uint8)
+    dev = torch.from_numpy(img).cuda()
+    for ksize in (9, 11, 15):
+        got = ops.median_blur(dev, ksize).cpu().numpy()
+        for b in range(2):
+            assert np.array_equal(got[b], median_blur(img[b], ksize)), (b, ksize)
+    assert np.array_equal(ops.median_blur(dev, 1).cpu().numpy(), img)
+    for ksize in (0, 4, 256, -3):
         with pytest.raises(ValueError):
-            ops.median_blur(img, ksize)
+            ops.median_blur(dev, ksize)
+    for ksize in (1, 4):
+        with pytest.raises(ValueError):
+            RAGSegmentation(img[0], median_blur=ksize)
+    rag = RAGSegmentation(img[0].copy(), slic_clust_num=12, median_blur=9)
+    assert np.array_equal(rag._dev_image.cpu().numpy(), median_blur(img[0], 9))
 
 
 @pytest.mark.parametrize("H,W,K,c", [(213, 320, 200, 0.65), (120, 160, 60, 0.65),
