@@ -11,14 +11,16 @@
 //
 // What differs from the kernels in dcd_seg.hip (which stay as the box-gather front end and as the
 // plain body for segments whose colours do not fit a table):
-//   * ONE barrier per Lloyd round.  The accumulators are three buffers used in turn (round r adds
-//     into buffer r % 3; after the barrier of round r every wave clears its share of buffer
-//     (r - 1) % 3, which all waves finished reading before they reached that barrier, and which is
-//     next added to after the barrier of round r + 1).  After the barrier EVERY wave folds the
-//     buffer itself, moves the centres and applies the stop rule: the same instructions on the same
-//     numbers, so all waves hold the same centres and take the same decision without a second
-//     barrier, and no wave waits for one wave's serial section.  The centres never pass through
-//     LDS: lane j of every wave holds centre j, and the distance loop reads them as scalars.
+//   * TWO barriers per Lloyd round and no clearing.  The accumulators are two buffers used in
+//     turn and never cleared (a round's sums are the buffer's totals minus the totals seen two
+//     rounds ago).  After the round's first barrier wave 0 alone folds the buffer, moves the centres
+//     and applies the stop rule, and leaves the new centres and the decision in LDS; after the
+//     second barrier every wave reads them (one LDS word per lane, 24 lane reads).  Every wave
+//     folding and updating for itself saved the second barrier but cost 8 x 200 vector
+//     instructions per round in a kernel whose vector pipe is the busiest unit (90 % by
+//     SQ_ACTIVE_INST_VALU): measured 3.77 -> 3.63 ms per stage at 64 images with the fold on one
+//     wave.  (Packed fp32 for the distances, two clusters per instruction, measured no gain:
+//     a v_pk_* takes the issue time of the two plain operations it replaces.)
 //   * no calls and no second body: an empty cluster is re-seeded by the whole block in line (the
 //     mask is the same in every wave, so the branch is uniform over the block), and a segment
 //     whose colours overflow the table is put on the next tier's list (larger table) -- the last
@@ -76,7 +78,9 @@ __host__ __device__ constexpr int tier_copies(int km) { return 256 / km; }
 __host__ __device__ constexpr size_t tier_lds_bytes(int km, int cap) {
     // table + counts + colour indices (6 B per pixel of capacity), two accumulator buffers,
     // the 64-bit slots, 16 words of flags
-    return (size_t)cap * 6 + (size_t)2 * km * 4 * tier_copies(km) * 4 + (size_t)km * 8 + 64;
+    // the centres of the round (3 km floats)
+    return (size_t)cap * 6 + (size_t)2 * km * 4 * tier_copies(km) * 4 + (size_t)km * 8 + 64 +
+           (size_t)km * 3 * 4;
 }
 
 constexpr int tier_waves_per_simd(int km, int cap, int threads) {
@@ -103,6 +107,8 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     uint32_t* acc = reinterpret_cast<uint32_t*>(idx + CAP);
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(acc + 2 * BUF);
     int* flags = reinterpret_cast<int*>(slots + KM);
+    float* cen = reinterpret_cast<float*>(flags + 16);      // [cluster][component], written by wave 0
+    int& s_round = flags[5];                               // bit 0: stop, bit 1: a cluster ran empty
     int& s_full = flags[0];
     int& s_unique = flags[1];                              // ([2]: the ticket)
     int& s_joins = flags[3];
@@ -289,7 +295,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     const int nloop = s_unique;
     TIER_MARK(2)
 
-    // ---- Lloyd rounds (:85-107), one barrier each.  Lane layout of the per-round state: the
+    // ---- Lloyd rounds (:85-107).  Lane layout of wave 0's per-round state: the
     // 64 lanes of a wave cover the KM x 4 rows {count, sum0, sum1, sum2} of the accumulators, GL
     // lanes per cluster and GL / 4 per row; lane (j, f) holds field f of cluster j after the fold
     // and, for f = 1..3, component f - 1 of centre j, its previous value and its shift.
@@ -297,8 +303,10 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     constexpr int FL = GL / 4;                             // lanes per row
     const int cj = lane / GL, cf = (lane / FL) & 3;        // this lane's cluster and field
     const bool comp = cf >= 1 && cj < k && (lane & (FL - 1)) == 0;   // holds a centre component
+    // lane that owns entry (cj, cf - 1) of the centres in LDS
+    const bool holds = cf >= 1 && (lane & (FL - 1)) == 0;
     float wc = 1.0e18f, wo = 0.f;                          // unused slots: far from every 8-bit colour,
-    {                                                      // so the loop over all KM never picks them
+    if (wave == 0) {                                       // so the loop over all KM never picks them
         const int j = cj < k ? cj : 0, f = cf >= 1 ? cf - 1 : 0;
         float v0;
         if (A.use_hash) {
@@ -310,7 +318,9 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             v0 = A.centres[((size_t)gs * k + j) * 3 + f];
         }
         if (comp) wc = v0;
+        if (holds) cen[cj * 3 + (cf - 1)] = wc;
     }
+    __syncthreads();
     double old_sum = 0.0;
     int rounds = 0;
     uint32_t field = 0;                                    // lane (j, f): field f of cluster j, last round
@@ -326,11 +336,14 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     const int copy = lane & (COPIES - 1);
     while (true) {
         float c0[KM], c1[KM], c2[KM];                      // scalars: the same in every lane
+        {
+            const float cv = cen[lane < KM * 3 ? lane : 0];
 #pragma unroll
-        for (int j = 0; j < KM; ++j) {
-            c0[j] = lane_f(wc, j * GL + FL);
-            c1[j] = lane_f(wc, j * GL + 2 * FL);
-            c2[j] = lane_f(wc, j * GL + 3 * FL);
+            for (int j = 0; j < KM; ++j) {
+                c0[j] = lane_f(cv, 3 * j);
+                c1[j] = lane_f(cv, 3 * j + 1);
+                c2[j] = lane_f(cv, 3 * j + 2);
+            }
         }
         uint32_t* ab = acc + buf * BUF + copy;
         for (int i = tid; i < nloop; i += THREADS) {
@@ -375,32 +388,73 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             atomicAdd(a4 + 3 * COPIES, __umul24(weight, u2));
         }
         TIER_MARK(3)
-        __syncthreads();
+        __syncthreads();                                   // A: the round's sums are complete
         TIER_MARK(4)
-        // ---- fold (every wave): a buffer is KM * 4 rows of COPIES words = 16 words per lane
-        {
-            const uint4* src = reinterpret_cast<const uint4*>(acc + buf * BUF + lane * 16);
-            const uint4 p = src[0], q = src[1], r = src[2], t4 = src[3];
-            uint32_t tot = (((p.x + p.y) + (p.z + p.w)) + ((q.x + q.y) + (q.z + q.w))) +
-                           (((r.x + r.y) + (r.z + r.w)) + ((t4.x + t4.y) + (t4.z + t4.w)));
-            if (FL == 2) tot += (uint32_t)__builtin_amdgcn_mov_dpp((int)tot, 0xb1, 0xf, 0xf, true);   // lane ^ 1
-            if (buf == 0) {
-                field = tot - seen0;
-                seen0 = tot;
-            } else {
-                field = tot - seen1;
-                seen1 = tot;
+        uint32_t nj = 0;
+        // centre update + stop rule (:93-107) on wave 0's lanes; leaves the new centres and the
+        // decision in LDS
+        auto update = [&](float drawn) {
+            // one division for all components
+            float shift = 0.f;
+            if (comp) {
+                wc = nj ? __fdiv_rn((float)field, (float)nj) : drawn;      // or the re-sampled pixel (:101)
+                shift = fabsf(__fsub_rn(wc, wo));
+            }
+            // float32 sums in cluster order (:102): the shifts of component f move to lanes
+            // 16 f .. 16 f + KM - 1, a running sum along each row of 16 lanes adds them in order (after
+            // s steps the lanes up to s hold their exact prefix), lane 16 f + k - 1 has the total
+            const int from = (lane & 15) * GL + ((lane >> 4) + 1) * FL;
+            const float moved = __shfl(shift, from);        // every lane takes part: not under the test
+            const float x = ((lane >> 4) < 3 && (lane & 15) < k) ? moved : 0.f;
+            float run = x;
+#pragma unroll
+            for (int sft = 1; sft < KM; ++sft) {
+                const float up = __int_as_float(
+                    __builtin_amdgcn_update_dpp(0, __float_as_int(run), 0x111, 0xf, 0xf, true));   // row_shr:1
+                run = __fadd_rn(up, x);
+            }
+            const float sh0 = lane_f(run, k - 1), sh1 = lane_f(run, 16 + k - 1), sh2 = lane_f(run, 32 + k - 1);
+            const double cent_sum = ((double)sh0 + (double)sh1) + (double)sh2;
+            rounds += 1;
+            const int stop = (fabs(old_sum - cent_sum) < 0.1 || rounds >= A.max_rounds) ? 1 : 0;
+            if (holds) cen[cj * 3 + (cf - 1)] = wc;
+            if (lane == 0) s_round = stop;
+            old_sum = cent_sum;
+            wo = wc;
+        };
+        if (wave == 0) {
+            // ---- fold: a buffer is KM * 4 rows of COPIES words = 16 words per lane
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(acc + buf * BUF + lane * 16);
+                const uint4 p = src[0], q = src[1], r = src[2], t4 = src[3];
+                uint32_t tot = (((p.x + p.y) + (p.z + p.w)) + ((q.x + q.y) + (q.z + q.w))) +
+                               (((r.x + r.y) + (r.z + r.w)) + ((t4.x + t4.y) + (t4.z + t4.w)));
+                if (FL == 2) tot += (uint32_t)__builtin_amdgcn_mov_dpp((int)tot, 0xb1, 0xf, 0xf, true);   // lane ^ 1
+                if (buf == 0) {
+                    field = tot - seen0;
+                    seen0 = tot;
+                } else {
+                    field = tot - seen1;
+                    seen1 = tot;
+                }
+            }
+            nj = (uint32_t)__shfl((int)field, lane & ~(GL - 1));   // the cluster's count
+            const unsigned long long empty = __ballot(cj < k && (lane & (GL - 1)) == 0 && nj == 0);
+            if (empty == 0ull) {
+                update(wc);
+            } else if (lane == 0) {
+                s_round = 2;
+                *reinterpret_cast<unsigned long long*>(&flags[6]) = empty;
             }
         }
-        const uint32_t nj = (uint32_t)__shfl((int)field, lane & ~(GL - 1));   // the cluster's count
-        // ---- empty clusters (:101), re-seeded by the whole block: the mask is the same in every
-        // wave.  Cluster j takes the segment's pixel with the smallest resample_key (dcd_common.h).
-        float drawn = wc;
-        const unsigned long long empty = __ballot(cj < k && (lane & (GL - 1)) == 0 && nj == 0);
-        if (empty) {
+        __syncthreads();                                   // B: centres and decision are in LDS
+        int decision = *reinterpret_cast<volatile int*>(&s_round);
+        if (decision & 2) {
+            // ---- empty clusters (:101), re-seeded by the whole block.  Cluster j takes the segment's
+            // pixel with the smallest resample_key (dcd_common.h).
             if (tid < KM) slots[tid] = ~0ull;
             __syncthreads();
-            unsigned long long m = empty;
+            unsigned long long m = *reinterpret_cast<volatile unsigned long long*>(&flags[6]);
             while (m) {
                 const int j = (__ffsll((long long)m) - 1) / GL;
                 m &= m - 1;
@@ -420,36 +474,16 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
                 if (lane == 0 && best != ~0ull) atomicMin(&slots[j], best);
             }
             __syncthreads();
-            if (comp && nj == 0) drawn = (float)A.lab[(img + (uint32_t)slots[cj]) * 3 + (cf - 1)];
+            if (wave == 0) {
+                float drawn = wc;
+                if (comp && nj == 0) drawn = (float)A.lab[(img + (uint32_t)slots[cj]) * 3 + (cf - 1)];
+                update(drawn);
+            }
+            __syncthreads();
+            decision = *reinterpret_cast<volatile int*>(&s_round);
         }
-        // ---- centre update + stop rule (:93-107): one division for all components
-        float shift = 0.f;
-        if (comp) {
-            wc = nj ? __fdiv_rn((float)field, (float)nj) : drawn;      // or the re-sampled pixel (:101)
-            shift = fabsf(__fsub_rn(wc, wo));
-        }
-        // float32 sums in cluster order (:102): the shifts of component f move to lanes
-        // 16 f .. 16 f + KM - 1, a running sum along each row of 16 lanes adds them in order (after
-        // s steps the lanes up to s hold their exact prefix), lane 16 f + k - 1 has the total
-        const int from = (lane & 15) * GL + ((lane >> 4) + 1) * FL;
-        const float moved = __shfl(shift, from);            // every lane takes part: not under the test
-        const float x = ((lane >> 4) < 3 && (lane & 15) < k) ? moved : 0.f;
-        float run = x;
-#pragma unroll
-        for (int sft = 1; sft < KM; ++sft) {
-            const float up = __int_as_float(
-                __builtin_amdgcn_update_dpp(0, __float_as_int(run), 0x111, 0xf, 0xf, true));   // row_shr:1
-            run = __fadd_rn(up, x);
-        }
-        const float sh0 = lane_f(run, k - 1), sh1 = lane_f(run, 16 + k - 1), sh2 = lane_f(run, 32 + k - 1);
-        const double cent_sum = ((double)sh0 + (double)sh1) + (double)sh2;
-        rounds += 1;
-        const int stop = __builtin_amdgcn_readfirstlane(
-            (fabs(old_sum - cent_sum) < 0.1 || rounds >= A.max_rounds) ? 1 : 0);
         TIER_MARK(5)
-        if (stop) break;
-        old_sum = cent_sum;
-        wo = wc;
+        if (__builtin_amdgcn_readfirstlane(decision) & 1) break;
         buf ^= 1;
     }
 
@@ -627,7 +661,7 @@ void dcd_dedup_kernel(TierArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the workgroups draw tickets for the entries of their list: segments differ in size and in
     // rounds by an order of magnitude, so a fixed split would leave a long tail
-    int* ticket = reinterpret_cast<int*>(smem + tier_lds_bytes(KM, CAP) - 64) + 2;
+    int* ticket = reinterpret_cast<int*>(smem + tier_lds_bytes(KM, CAP) - 64 - KM * 3 * 4) + 2;
     const int count = A.L.hdr[A.tier];
     while (true) {
         if (threadIdx.x == 0) *ticket = atomicAdd(&A.L.hdr[8 + A.tier], 1);
