@@ -700,8 +700,27 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
         for (int j = 0; j < R; ++j) slot[j] = -1;
         unsigned tied = 0;                  // bit j: the best key of pixel j may have been met again
         if (MODE == 0) {
-            int best[R], best2[R];          // lowest and second lowest key met so far
+            // Issue costs measured on this chip (tools/issue_rate.hip, profiles/r03_issue_rate.txt): a
+            // wave64 add / subtract / logic operation (v_bitop3 included) whose operands are vector
+            // registers or inline constants takes 2 cycles of its SIMD; everything else used here
+            // (v_dot4, v_mad_i32_i24, v_min, v_med3, compares, selects) and ANY operation with a
+            // scalar-register operand takes 4.  Per (row, candidate) the loop is
+            //     pc  = v_dot4(px, c.lab)                  4
+            //     key = v_mad_i32_i24(pc, -2 S^2, Xj)      4
+            //     kp  = v_bitop3: (key & ~M) | slot        2   mask and slot in vector registers
+            //     b2  = v_med3(kp, best, b2)               4
+            //     best = v_min(best, kp)                   4
+            //     Xj -= By                                 2   By copied to a vector register
+            // The winner's slot rides in the low bits of the key (M = 15 for a tile with at most 16
+            // candidates, else 63), which replaces the compare / select pair of a plain arg-min
+            // (measured: 0.514 -> 0.489 ms per launch at 128 images).  Keys are therefore compared
+            // above those bits only: a row in which some pixel's two lowest packed keys agree there
+            // ((best ^ b2) <= M) is replayed with full keys further down.
+            int best[R], best2[R];          // lowest and second lowest packed key met so far
             uint32_t T[R];
+            const int mbits = m <= 16 ? 15 : 63;                       // wave uniform
+            int maskv, sv;                                             // ~M and the slot, per lane
+            asm("v_mov_b32 %0, %1" : "=v"(maskv) : "s"(~mbits));
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 best[j] = best2[j] = REL ? 0x7fffffff : -1;
@@ -711,29 +730,34 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                     T[j] = pp * P.S2 + P.cw2 * (uint32_t)(xr * xr + (wy0 + j) * (wy0 + j));
                 }
             }
-            // The column test is the only per-lane condition: the lanes outside the candidate's
-            // columns sit out its whole body (one exec mask per candidate), the row tests are
-            // wave uniform.  ALL: every row of the wave is inside the candidate's window (the
-            // common case).  Equal keys: best2 follows the second lowest key with one median
-            // per evaluation (best <= best2 always holds, so median(key, best, best2) is the new
-            // second lowest); a pixel whose two lowest keys are equal is replayed exactly below.
+            auto full_key = [&](const int8v& c, int j) {
+                const int pc = (int)__builtin_amdgcn_udot4(px[j], (uint32_t)c[2], 0u, false);
+                int key = __mul24(nS2x2, pc) + (__mul24(-c[5], xr) + (c[4] - c[6] * (wy0 + j)));
+                if (!REL) key = (int)((uint32_t)key + T[j]);
+                return key;
+            };
             auto eval = [&](int s, const int8v& c, int t0, bool all_rows) {
                 if ((unsigned)(xr - c[0] + S) < (unsigned)twoS) {
-                    const int X = __mul24(-c[5], xr) + (c[4] - c[6] * wy0);
+                    int Xj = __mul24(-c[5], xr) + (c[4] - c[6] * wy0);
+                    int byv;
+                    asm("v_mov_b32 %0, %1" : "=v"(byv) : "s"(c[6]));
+                    asm("v_mov_b32 %0, %1" : "=v"(sv) : "s"(s));
                     const uint32_t cl = (uint32_t)c[2];
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         if (all_rows || (unsigned)(t0 + j) < (unsigned)twoS) {
                             const int pc = (int)__builtin_amdgcn_udot4(px[j], cl, 0u, false);
-                            int key = __mul24(nS2x2, pc) + (X - j * c[6]);
+                            int key = __mul24(nS2x2, pc) + Xj;
                             if (!REL) key = (int)((uint32_t)key + T[j]);
-                            best2[j] = REL ? smed3(key, best[j], best2[j])
-                                           : (int)umed3((uint32_t)key, (uint32_t)best[j],
+                            const int kp = (int)__builtin_amdgcn_bitop3_b32(
+                                (uint32_t)key, (uint32_t)maskv, (uint32_t)sv, 0xeau);   // (a & b) | c
+                            best2[j] = REL ? smed3(kp, best[j], best2[j])
+                                           : (int)umed3((uint32_t)kp, (uint32_t)best[j],
                                                         (uint32_t)best2[j]);
-                            const bool lt = REL ? key < best[j] : (uint32_t)key < (uint32_t)best[j];
-                            best[j] = lt ? key : best[j];
-                            slot[j] = lt ? s : slot[j];
+                            best[j] = REL ? min(best[j], kp)
+                                          : (int)min((uint32_t)best[j], (uint32_t)kp);
                         }
+                        Xj -= byv;
                     }
                 }
             };
@@ -754,14 +778,39 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                 const int8v c = rec[1 + s];
                 eval(s, c, wy0 - c[1] + S, false);
             }
-            unsigned long long any_tie = 0ull;
+            unsigned long long any_near = 0ull;
 #pragma unroll
-            for (int j = 0; j < R; ++j) any_tie |= __builtin_amdgcn_ballot_w64(best2[j] == best[j]);
-            if (any_tie != 0ull) {                       // wave uniform, rarely taken
+            for (int j = 0; j < R; ++j) {
+                slot[j] = best[j] & mbits;
+                any_near |= __builtin_amdgcn_ballot_w64((uint32_t)(best[j] ^ best2[j]) <= (uint32_t)mbits);
+            }
+            if (any_near != 0ull) {                      // wave uniform
                 ASSIGN_COUNT(4);
+                // Rows that hold a pixel whose two lowest keys agree above the slot bits (or a pixel
+                // no candidate covers: both still at their start value): the whole wave goes over
+                // the row's candidates again with full keys.  The first strictly lower key wins
+                // (= the lowest centre index among equal keys); a pixel whose lowest full key is met
+                // twice goes on to the float64 replay below, as the reference compares rounded
+                // float64 distances.
 #pragma unroll
-                for (int j = 0; j < R; ++j)
-                    tied |= (best2[j] == best[j] && slot[j] >= 0) ? (1u << j) : 0u;
+                for (int j = 0; j < R; ++j) {
+                    if (__builtin_amdgcn_ballot_w64((uint32_t)(best[j] ^ best2[j]) <= (uint32_t)mbits) == 0ull)
+                        continue;
+                    int kb = 0, sb = -1;
+                    bool dup = false;
+                    for (int s = 0; s < m; ++s) {
+                        const int8v c = rec[1 + s];
+                        if ((unsigned)(wy0 + j - c[1] + S) >= (unsigned)twoS) continue;   // uniform
+                        if ((unsigned)(xr - c[0] + S) >= (unsigned)twoS) continue;
+                        const int key = full_key(c, j);
+                        const bool lt = sb < 0 || (REL ? key < kb : (uint32_t)key < (uint32_t)kb);
+                        dup = lt ? false : (dup || key == kb);
+                        kb = lt ? key : kb;
+                        sb = lt ? s : sb;
+                    }
+                    slot[j] = sb;
+                    tied |= (dup && sb >= 0) ? (1u << j) : 0u;
+                }
             }
         } else {
             typename KeyT<MODE>::type best[R];
@@ -996,9 +1045,11 @@ int key_mode(int S, double cw, bool* rel) {
     if (r != cw || cw < 1.0 || cw > 4096.0) return 2;
     double cw2 = cw * cw, S2 = (double)S * S;
     double span = (double)(TW + S) * (TW + S) + (double)(TILE_H_MAX + S) * (TILE_H_MAX + S);
-    bool fits32 = S2 * 195075.0 + cw2 * span < 4294967295.0 &&
+    // (128 below the ends of the range: the assignment kernel rounds keys down to a multiple of 64
+    // and keeps its start value above every key)
+    bool fits32 = S2 * 195075.0 + cw2 * span < 4294967295.0 - 128.0 &&
                   2.0 * cw2 * (TILE_H_MAX + TW + S) < 8388608.0 && 2.0 * S2 < 8388608.0;
-    *rel = fits32 && S2 * 195075.0 + cw2 * span < 2147483647.0;
+    *rel = fits32 && S2 * 195075.0 + cw2 * span < 2147483647.0 - 128.0;
     return fits32 ? 0 : 1;
 }
 
