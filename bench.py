@@ -218,7 +218,7 @@ def dcd_traffic(key, npix):
     """HBM bytes of one imgan_dcd_segments_listed call: the sort pass, the plan and the three tier
     launches (pmc_traffic.json holds the mean over the launches of a kernel name)."""
     parts = [pmc_traffic(key, "seg_scatter_kernel", npix), pmc_traffic(key, "seg_plan_kernel", npix),
-             pmc_traffic(key, "dcd_segment_kernel", npix)]
+             pmc_traffic(key, "dcd_dedup_kernel", npix)]
     if any(p is None for p in parts):
         return None
     return parts[0] + parts[1] + 3 * parts[2]
@@ -241,7 +241,7 @@ def run_config_rag(steps, warmup):
     redone = pipe.rag.finish(pipe.lab, pipe.slic.labels, pipe.c_factor) if pipe.rag is not None else 0
     ms = pipe.stage_times_ms()
     npix = B * H * W
-    prof = "profiles/r02_rag4k_kernel_summary.txt"
+    prof = "profiles/r03_rag4k_kernel_summary.txt"
     path_bytes = 6 + 6 + 63 + 7 + 8
     rec = {"config": "configs[2]: %d x %dx%d BGR, K=%d (n=%d, S=%d), median 7x7 + Lab + SLIC (9 rounds) "
                      "+ per-label means and adjacency + MST merge (c=0.65, on the device) + relabel" %
@@ -291,7 +291,7 @@ def run_config_mosaic(steps, warmup):
     npix = B * H * W
     t_bar = pipe.mean_lloyd_rounds()
     dcd_bytes = round(8.0 * t_bar + 13.0, 1)
-    prof = "profiles/r02_mosaic_kernel_summary.txt"
+    prof = "profiles/r03_mosaic_kernel_summary.txt"
     path_bytes = 6 + 63 + pipe.descriptor_bytes_per_px() + dcd_bytes
     rec = {"config": "configs[4] (one GPU's share): %d x %dx%d BGR, K=%d (n=%d, S=%d), Lab + SLIC + "
                      "CLD / EHD / CSD and dominant colours k=8 of every superpixel (%.1f Lloyd rounds per pixel)" %
@@ -300,7 +300,7 @@ def run_config_mosaic(steps, warmup):
            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
            "dcd_segments_at_round_cap": pipe.segments_at_round_cap(),
            "dcd_segments_left_to_streaming_rounds": int(segments_left),
-           "roofline": roofline_line("dcd_segment_kernel x3 tiers (+seg_scatter_kernel, seg_plan_kernel)",
+           "roofline": roofline_line("dcd_dedup_kernel x3 tiers (+seg_scatter_kernel, seg_plan_kernel)",
                                      ms["dcd_segments"], dcd_bytes, npix, profile=prof, bound="valu/lds",
                                      note="timed around the C call (imgan_dcd_segments_listed); SURVEY 8d "
                                           "figure 8*T+13*P; the Lloyd rounds run in LDS, compulsory HBM "
@@ -491,7 +491,7 @@ def main():
     if rank == 0:
         npix = B * H * W
         key = "%dx%d_K%d" % (W, H, K)
-        prof = "profiles/r02_bench_kernel_summary.txt"
+        prof = "profiles/r03_bench_kernel_summary.txt"
         stage_ms = pipe.stage_times_ms()           # HIP events on the launch stream, per C call
         # mean Lloyd rounds per pixel (a segment stops at its own round): the T of SURVEY 8d
         t_bar = pipe.mean_lloyd_rounds()
@@ -501,7 +501,11 @@ def main():
             roofline_line("slic_assign_kernel", stage_ms["slic_assign"], SLIC_ROUND_BYTES_PER_PX, npix,
                           traffic=pmc_traffic(key, "slic_assign_kernel", npix), profile=prof,
                           launches=num_iter - 1,
-                          note="moves the most HBM bytes of the step (9 x 7 B/px); instruction-issue bound"),
+                          bound="valu",
+                          note="moves the most HBM bytes of the step (9 x 7 B/px); bound by the vector pipe: "
+                               "SQ_ACTIVE_INST_VALU x 4 / SIMDs / cycles = 0.85 (profiles/r03_pmc_B64.txt), its "
+                               "integer ops (v_dot4, v_mad_i32_i24, v_med3, v_min) issue at 4 cycles per wave64 "
+                               "(profiles/r03_issue_rate.txt)"),
             roofline_line("bgr2lab_kernel", stage_ms["bgr2lab"], 6, npix, profile=prof,
                           traffic=pmc_traffic(key, "bgr2lab_kernel", npix)),
             roofline_line("csd_kernel", stage_ms["csd"], 3, npix, profile=prof,
@@ -528,17 +532,18 @@ def main():
                        "global_batch": B * world, "parallelism": "batch-sharded x%d" % world,
                        "library": os.path.relpath(LIB_PATH, ROOT)},
             # the dominant kernel by time: one C call (imgan_dcd_segments_listed) = the pass that sorts
-            # the pixels by segment + the three capacity tiers of dcd_segment_kernel, one launch each
+            # the pixels by segment + the three capacity tiers of dcd_dedup_kernel, one launch each
             "roofline": roofline_line(
-                "dcd_segment_kernel x3 tiers (+seg_scatter_kernel, seg_plan_kernel)",
+                "dcd_dedup_kernel x3 tiers (+seg_scatter_kernel, seg_plan_kernel)",
                 stage_ms["dcd_segments"], dcd_survey, npix,
-                traffic=dcd_traffic(key, npix), profile=prof, bound="valu/lds",
+                traffic=dcd_traffic(key, npix), profile=prof, bound="valu",
                 note="largest share of the step time; timed around the C call, i.e. the sum of the five "
                      "kernels it launches back to back.  Algorithmic bytes = SURVEY 8d's streaming figure "
                      "8*T + 13*P B/px with T = %.1f measured Lloyd rounds per pixel, P = 1; the rounds run "
                      "in LDS, so the HBM traffic it must move is 24 B/px (7 labels + Lab in, 8 list out, "
                      "8 list in, 1 assignment out; traffic above that is the sort's partial lines) and "
-                     "the kernel is VALU / LDS bound" % t_bar),
+                     "the kernels are bound by the vector pipe (SQ_ACTIVE_INST_VALU x 4 / SIMDs / cycles = 0.90 "
+                     "on the small tier, profiles/r03_pmc_B64.txt)" % t_bar),
             "roofline_kernels": others,
             "dcd_segments_at_round_cap": pipe.segments_at_round_cap(),
             "dcd_segments_left_to_streaming_rounds": int(segments_left),

@@ -3,8 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 S=gpurun_out/rf3
-python tools/pmc_traffic.py $S/pmc_fetch $S/pmc_write $((64*1920*1080)) 1920x1080_K400 > /dev/null
-python tools/pmc_traffic.py $S/pmcrag_fetch $S/pmcrag_write $((4*3840*2160)) 3840x2160_K2000 > /dev/null
+cp $S/pmc_traffic.json profiles/pmc_traffic.json
 cp $S/bench.json profiles/r03_bench.json
 cp $S/kt/b_kernel_stats.csv profiles/r03_bench_kernel_stats.csv
 cp $S/pmc_B64.txt profiles/r03_pmc_B64.txt
