@@ -15,6 +15,16 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 }
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;   // one global_load_dword at any address
 
+// Lab of the pixel at (x, y) of image b as L | a << 8 | b << 16 | junk << 24: one unaligned dword
+// load; the very last pixel of the batch is read one byte early so that the load stays in bounds.
+// x and y are clamped into the image (positions come from a list in scratch memory).
+__device__ __forceinline__ uint32_t lab_at(const uint8_t* __restrict__ lab, size_t img_px, int x, int y,
+                                           int H, int W, size_t last_px) {
+    const size_t gp = img_px + (size_t)(uint32_t)(__mul24(min(max(y, 0), H - 1), W) + min(max(x, 0), W - 1));
+    const uint32_t sh = gp >= last_px ? 1u : 0u;
+    return *reinterpret_cast<const u32_unaligned*>(lab + gp * 3 - sh) >> (8u * sh);
+}
+
 // Capacity tiers (pixels a workgroup holds in LDS at 6 B each, and its thread count).
 // 768 threads = 3 waves on each SIMD of the CU per workgroup, 6 with the second workgroup: measured
 // against 512 / 640 / 896 / 1024 threads (5.6 / 6.3 / 8.0 / 7.4 ms where this takes 5.1): the
@@ -36,22 +46,27 @@ constexpr int DEDUP_PROBES = 64;                       // linear probes before a
 
 // ---- pixel lists (imgan_dcd_segments_listed).  With the pixel count of every segment known up
 // front (the last SLIC round has it), one streaming pass sorts the pixels by segment: every
-// segment owns a contiguous run of {Lab, y << 16 | x} entries.  The segment kernel then loads its
-// run with straight reads instead of scanning its bounding box (about 2.5 cells per pixel for a
-// superpixel, with a ballot and an LDS atomic per 64 cells), and every segment goes directly to
-// the capacity tier that fits it.
+// segment owns a contiguous run of positions y << 16 | x (4 B per pixel; the pass reads the labels
+// only).  The segment kernel then walks its run with straight reads and fetches the colours by
+// position -- a chunk of a run is a piece of an image row, so neighbouring lanes read neighbouring
+// bytes -- instead of scanning its bounding box (about 2.5 cells per pixel for a superpixel, with
+// a ballot and an LDS atomic per 64 cells), and every segment goes directly to the capacity tier
+// that fits it.  (Lists of {Lab, position}, 8 B per pixel, had the sorting pass read the colours
+// too and write twice as much.  Its time is the same either way, 2.0 ms for 256 x 1080p -- it
+// waits for its reserving atomics and for its stores to be acknowledged, not for bandwidth:
+// measured with the stores, the atomics and the ranking removed in turn -- but the lists now take
+// 2.1 GB instead of 4.2 for that batch.)
 struct SegLists {
     int* hdr;               // [64]: 0..3 length of the lists below, 8..11 their ticket counters
     uint32_t* offsets;      // [nsegs] start of every segment's run (inside its image's H*W slab)
     uint32_t* ends;         // [nsegs] end of the run: start + count, clamped to the slab
     uint32_t* cursor;       // [nsegs] entries written so far
     int* tier[4];           // [nsegs] each: segment ids by tier; [3]: what the dedup tiers hand to the plain body
-    uint32_t* spix;         // [B*H*W] Lab of the listed pixels
     uint32_t* sxy;          // [B*H*W] y << 16 | x
 };
 
 inline size_t seg_lists_bytes(size_t nsegs, size_t npx) {
-    return 256 + 7 * imgan::align_up(nsegs * 4, 256) + 2 * imgan::align_up(npx * 4, 256);
+    return 256 + 7 * imgan::align_up(nsegs * 4, 256) + imgan::align_up(npx * 4, 256);
 }
 
 inline SegLists bind_lists(void* scratch, size_t nsegs, size_t npx) {
@@ -69,8 +84,6 @@ inline SegLists bind_lists(void* scratch, size_t nsegs, size_t npx) {
         L.tier[t] = (int*)p;
         p += imgan::align_up(nsegs * 4, 256);
     }
-    L.spix = (uint32_t*)p;
-    p += imgan::align_up(npx * 4, 256);
     L.sxy = (uint32_t*)p;
     return L;
 }

@@ -241,8 +241,7 @@ struct ScatterTable {
 };
 
 template <bool COUNT_ONLY>
-__global__ __launch_bounds__(256) void seg_scatter_kernel(const uint8_t* __restrict__ lab,
-                                                          const int32_t* __restrict__ labels, int B,
+__global__ __launch_bounds__(256) void seg_scatter_kernel(const int32_t* __restrict__ labels, int B,
                                                           int H, int W, int nseg, SegLists L,
                                                           int32_t* __restrict__ counts) {
     __shared__ ScatterTable T;
@@ -254,18 +253,12 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const uint8_t* __restr
         T.key[tid] = -1;
         T.cnt[tid] = 0u;
     }
-    const size_t last_px = (size_t)B * H * W - 1;
     int lbl[SC_ROWS];
-    uint32_t px[SC_ROWS];
 #pragma unroll
     for (int u = 0; u < SC_ROWS; ++u) {                 // all loads first, clamped not branched
         const int y = y0 + u < H ? y0 + u : H - 1;
         const size_t gp = ((size_t)b * H + y) * W + xc;
         lbl[u] = labels[gp];
-        if (!COUNT_ONLY) {
-            const uint32_t sh = gp == last_px ? 1u : 0u;
-            px[u] = *reinterpret_cast<const u32_unaligned*>(lab + gp * 3 - sh) >> (8u * sh);
-        }
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -323,10 +316,7 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const uint8_t* __restr
                 const int slot = where[u] & 255;
                 // 64-bit: the cursor of a label map that disagrees with the counts may run on
                 const unsigned long long dst = (unsigned long long)T.base[slot] + (uint32_t)(where[u] >> 8);
-                if (dst < T.end[slot]) {
-                    L.spix[dst] = px[u] & 0xffffffu;
-                    L.sxy[dst] = xy;
-                }
+                if (dst < T.end[slot]) L.sxy[dst] = xy;
             }
         }
         // more labels in the block than table slots: these runs reserve their places one by one
@@ -348,10 +338,7 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const uint8_t* __restr
                 if (mine) {
                     const unsigned long long dst =
                         (unsigned long long)L.offsets[gs] + first + (uint32_t)__popcll(who & below);
-                    if (dst < L.ends[gs]) {
-                        L.spix[dst] = px[u] & 0xffffffu;
-                        L.sxy[dst] = xy;
-                    }
+                    if (dst < L.ends[gs]) L.sxy[dst] = xy;
                 }
             }
             if (mine) pending = -1;
@@ -495,11 +482,11 @@ __device__ __forceinline__ void segment_body(
         for (int i0 = 0; i0 < nrun; i0 += THREADS * LU) {
             uint32_t v[LU], xy[LU];
 #pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int i = min(i0 + u * THREADS + tid, nrun - 1);
-                v[u] = L.spix[run_at + i];
-                xy[u] = L.sxy[run_at + i];
-            }
+            for (int u = 0; u < LU; ++u) xy[u] = L.sxy[run_at + min(i0 + u * THREADS + tid, nrun - 1)];
+#pragma unroll
+            for (int u = 0; u < LU; ++u)                   // the colours, by position
+                v[u] = lab_at(lab, img, (int)(xy[u] & 0xffffu), (int)(xy[u] >> 16), H, W,
+                              (size_t)B * H * W - 1);
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
                 const int i = i0 + u * THREADS + tid;
@@ -1255,7 +1242,7 @@ extern "C" int imgan_label_counts(const int32_t* labels, int B, int H, int W, in
     IMGAN_HIP(hipMemsetAsync(counts, 0, (size_t)B * nseg * 4, st));
     dim3 grid((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, SC_ROWS), (unsigned)B);
     SegLists none = {};
-    hipLaunchKernelGGL(seg_scatter_kernel<true>, grid, dim3(256), 0, st, (const uint8_t*)nullptr,
+    hipLaunchKernelGGL(seg_scatter_kernel<true>, grid, dim3(256), 0, st,
                        labels, B, H, W, nseg, none, counts);
     return imgan::check_launch("seg_scatter_kernel<count>");
 }
@@ -1296,7 +1283,7 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
     hipLaunchKernelGGL(seg_plan_kernel, dim3((unsigned)B), dim3(1024), 0, st, counts, bbox, nseg, H, W, L,
                        cap0, cap1, CAP_LARGE, n_big_out);
     dim3 gsc((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, SC_ROWS), (unsigned)B);
-    hipLaunchKernelGGL(seg_scatter_kernel<false>, gsc, dim3(256), 0, st, lab, labels, B, H, W, nseg, L,
+    hipLaunchKernelGGL(seg_scatter_kernel<false>, gsc, dim3(256), 0, st, labels, B, H, W, nseg, L,
                        (int32_t*)nullptr);
     unsigned long long* stt = (unsigned long long*)stats;
     if (dedup) {

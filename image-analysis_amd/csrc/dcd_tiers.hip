@@ -60,7 +60,7 @@ __device__ unsigned long long tier_timing[32];
 
 struct TierArgs {
     const uint8_t* lab;
-    int H, W, nseg, k, use_hash;
+    int B, H, W, nseg, k, use_hash;
     uint32_t seed;
     float* centres;
     uint8_t* assign;                    // may be NULL: the map is not written
@@ -170,11 +170,11 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             if (*reinterpret_cast<volatile int*>(&s_full)) break;
             uint32_t v[LU], xy[LU];
 #pragma unroll
-            for (int u = 0; u < LU; ++u) {
-                const int i = min(i0 + u * THREADS + tid, n - 1);
-                v[u] = L.spix[run_at + i];
-                xy[u] = L.sxy[run_at + i];
-            }
+            for (int u = 0; u < LU; ++u) xy[u] = L.sxy[run_at + min(i0 + u * THREADS + tid, n - 1)];
+#pragma unroll
+            for (int u = 0; u < LU; ++u)                   // the colours, by position
+                v[u] = lab_at(A.lab, img, (int)(xy[u] & 0xffffu), (int)(xy[u] >> 16), H, W,
+                              (size_t)A.B * H * W - 1);
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
                 const int i = i0 + u * THREADS + tid;
@@ -708,7 +708,7 @@ int imgan_dcd_launch_dedup_tiers(const uint8_t* lab, int B, int H, int W, int ns
                                  const SegLists& L, hipStream_t st) {
     TierArgs A;
     A.lab = lab;
-    A.H = H, A.W = W, A.nseg = nseg, A.k = k, A.use_hash = use_hash;
+    A.B = B, A.H = H, A.W = W, A.nseg = nseg, A.k = k, A.use_hash = use_hash;
     A.seed = seed;
     A.centres = centres;
     A.assign = assign;

@@ -272,9 +272,10 @@ int imgan_dcd_segments_boxed(const uint8_t* lab, const int32_t* labels, int B, i
 
 /* The same with bounding boxes AND pixel counts known (bbox int32 [B][nseg][4], counts int32
  * [B][nseg]; imgan_label_bbox / imgan_label_counts, or the last SLIC round and
- * imgan_slic_label_counts): one streaming pass sorts the pixels by segment into list_scratch
- * (imgan_dcd_list_bytes() bytes, 8 per pixel), every segment's workgroup then reads its own
- * run instead of scanning its bounding box, and goes straight to the LDS tier that fits it
+ * imgan_slic_label_counts): one streaming pass sorts the pixel positions by segment into
+ * list_scratch (imgan_dcd_list_bytes() bytes, 4 per pixel), every segment's workgroup then walks
+ * its own run (fetching the colours by position) instead of scanning its bounding box, and goes
+ * straight to the LDS tier that fits it
  * (np.where(clusters == seg) of mpeg7Descriptors.py:28-33 for all segments in one pass).
  * Same results as imgan_dcd_segments.  Needs W <= 65536 and B*H*W < 2^32.  Counts that
  * disagree with `labels` lose the surplus pixels (never memory safety). */
