@@ -227,108 +227,199 @@ __global__ __launch_bounds__(1024) void seg_plan_kernel(const int32_t* __restric
 }
 
 // The pass that fills the runs (COUNT_ONLY: just counts the pixels of every label, for callers
-// that have no counts).  One block = 256 columns x SC_ROWS rows, every lane one column.  The
-// labels of a block are tallied in a small LDS table (one LDS atomic per run of equal labels in a
-// wave row, which also ranks the pixels of the run); then one global atomic per label and block
-// reserves the block's share of the segment's run, and the pixels are written behind it.
-constexpr int SC_ROWS = 8, SC_SLOTS = 128;         // 4 and 16 rows measured: 0.78 / 0.60 ms where 8 takes 0.54
+// that have no counts).  One block = SC_WAVES rows x 512 columns: a wave takes a row, a lane
+// SC_PX consecutive pixels of it (two 16-byte loads).
+//   ranking: a piece that is one run of one label (the rule) joins the equal pieces of the lanes
+//     beside it; the first lane of such a run of lanes enters the label in a small LDS table and
+//     reserves for all of them with one returning LDS atomic; a piece with a boundary in it does
+//     that run by run for itself.  About 20 vector instructions per pixel.  (Ranking wave row by
+//     wave row with one ballot loop per distinct label of the row took 119 per pixel, 90 % of
+//     that form's time.)
+//   reservation: one global atomic per label and block takes the block's share of the segment's run.
+//   output: the positions go to an LDS buffer in (label, rank) order, and every label's share is
+//     copied out by the whole block with consecutive lanes on consecutive entries: whole sectors.
+//     (Each lane storing its own eight entries, 32 bytes apart from its neighbour's, held the
+//     pass at 2.2 TB/s.)
+constexpr int SC_PX = 8, SC_WAVES = 4, SC_BLOCK_ROWS = SC_WAVES, SC_BLOCK_W = 64 * SC_PX, SC_SLOTS = 128;
+constexpr int SC_THREADS = 64 * SC_WAVES, SC_BLOCK_PX = SC_THREADS * SC_PX;
 
 struct ScatterTable {
     int key[SC_SLOTS];
     uint32_t cnt[SC_SLOTS];
     uint32_t base[SC_SLOTS];
     uint32_t end[SC_SLOTS];
+    uint32_t off[SC_SLOTS];     // where the label's share starts in the staging buffer
+    int active[SC_SLOTS];       // the slots in use, closed up
+    int nactive, wave0_total, wave0_active;
 };
 
 template <bool COUNT_ONLY>
-__global__ __launch_bounds__(256) void seg_scatter_kernel(const int32_t* __restrict__ labels, int B,
-                                                          int H, int W, int nseg, SegLists L,
-                                                          int32_t* __restrict__ counts) {
+__global__ __launch_bounds__(SC_THREADS) void seg_scatter_kernel(
+    const int32_t* __restrict__ labels, int B, int H, int W, int nseg, SegLists L,
+    int32_t* __restrict__ counts) {
     __shared__ ScatterTable T;
-    const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
-    const int y0 = blockIdx.y * SC_ROWS;
-    const int x = blockIdx.x * 256 + tid;
-    const int xc = x < W ? x : W - 1;
+    __shared__ uint32_t staged[COUNT_ONLY ? 1 : SC_BLOCK_PX];
+    const int b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int y = blockIdx.y * SC_BLOCK_ROWS + wave;
+    const int x0 = blockIdx.x * SC_BLOCK_W + lane * SC_PX;
     if (tid < SC_SLOTS) {
         T.key[tid] = -1;
         T.cnt[tid] = 0u;
     }
-    int lbl[SC_ROWS];
+    static_assert(SC_PX == 8, "a piece is loaded as two int4");
+    static_assert(SC_SLOTS == 128 && SC_THREADS >= 128, "the table is closed up by two waves");
+    int cur[SC_PX];
+    {
+        // clamped, not branched; 16-byte loads where the piece is aligned and whole
+        const int yc = y < H ? y : H - 1;
+        const int32_t* row = labels + ((size_t)b * H + yc) * W;
+        if ((W & 3) == 0 && x0 + SC_PX <= W && (reinterpret_cast<uintptr_t>(labels) & 15) == 0) {
+            const int4 lo = *reinterpret_cast<const int4*>(row + x0);
+            const int4 hi = *reinterpret_cast<const int4*>(row + x0 + 4);
+            cur[0] = lo.x, cur[1] = lo.y, cur[2] = lo.z, cur[3] = lo.w;
+            cur[4] = hi.x, cur[5] = hi.y, cur[6] = hi.z, cur[7] = hi.w;
+        } else {
 #pragma unroll
-    for (int u = 0; u < SC_ROWS; ++u) {                 // all loads first, clamped not branched
-        const int y = y0 + u < H ? y0 + u : H - 1;
-        const size_t gp = ((size_t)b * H + y) * W + xc;
-        lbl[u] = labels[gp];
+            for (int u = 0; u < SC_PX; ++u) cur[u] = row[min(x0 + u, W - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < SC_PX; ++u) {
+            const bool ok = x0 + u < W && y < H && cur[u] >= 0 && cur[u] < nseg;
+            cur[u] = ok ? cur[u] : -1;
+        }
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long upto = below | (1ull << lane);          // lanes 0 .. this one
+    // table slot of a label (entered if new), 255 when the table is full
+    auto slot_of = [&](int c) {
+        int probe_at = (int)(((uint32_t)c * 0x9e3779b1u) >> 25);
+        for (int probe = 0; probe < SC_SLOTS; ++probe) {
+            const int old = atomicCAS(&T.key[probe_at], -1, c);
+            if (old == -1 || old == c) return probe_at;
+            probe_at = (probe_at + 1) & (SC_SLOTS - 1);
+        }
+        return 255;
+    };
     // where[u]: table slot | rank in the block's share << 8; -1: no pixel; slot 255: table full
-    int where[SC_ROWS];
+    int len_at[SC_PX], where[SC_PX];
+    {
+        int run_end = SC_PX;
 #pragma unroll
-    for (int u = 0; u < SC_ROWS; ++u) {
-        const bool ok = x < W && y0 + u < H && lbl[u] >= 0 && lbl[u] < nseg;
-        int pending = ok ? lbl[u] : -1;
-        where[u] = -1;
-        while (true) {
-            const unsigned long long act = __ballot(pending >= 0);
-            if (act == 0ull) break;
-            const int leader = __ffsll((long long)act) - 1;
-            const int cur = __shfl(pending, leader);
-            const bool mine = pending == cur;
-            const unsigned long long who = __ballot(mine);
-            int idx = 255, first = 0;
-            if (lane == leader) {
-                int probe_at = (int)(((uint32_t)cur * 0x9e3779b1u) >> 25);
-                for (int probe = 0; probe < SC_SLOTS; ++probe) {
-                    const int old = atomicCAS(&T.key[probe_at], -1, cur);
-                    if (old == -1 || old == cur) {
-                        idx = probe_at;
-                        break;
-                    }
-                    probe_at = (probe_at + 1) & (SC_SLOTS - 1);
-                }
-                if (idx != 255) first = (int)atomicAdd(&T.cnt[idx], (uint32_t)__popcll(who));
-            }
-            idx = __shfl(idx, leader);
-            first = __shfl(first, leader);
-            if (mine) {
-                where[u] = idx | ((first + __popcll(who & below)) << 8);
-                pending = -1;
-            }
+        for (int u = SC_PX - 1; u >= 0; --u) {
+            if (u < SC_PX - 1 && cur[u + 1] != cur[u]) run_end = u + 1;
+            len_at[u] = run_end - u;                      // read at the first pixel of a run only
         }
     }
-    __syncthreads();
-    if (tid < SC_SLOTS && T.key[tid] >= 0) {
-        const size_t gs = (size_t)b * nseg + T.key[tid];
-        if (COUNT_ONLY) {
-            atomicAdd(&counts[gs], (int)T.cnt[tid]);
+    {
+        const bool whole = len_at[0] == SC_PX && cur[0] >= 0;
+        const int c0 = whole ? cur[0] : -1 - lane;                   // never equal to a neighbour's
+        const int left = __shfl_up(c0, 1);
+        const bool head = lane == 0 || c0 != left;
+        const unsigned long long heads = __ballot(head);             // bit 0 is always set
+        const int first_lane = 63 - __clzll((long long)(heads & upto));
+        const unsigned long long later = heads & ~upto;
+        const int next_head = later ? __ffsll((long long)later) - 1 : 64;
+        int packed = -1;
+        if (whole && head) {
+            const int idx = slot_of(c0);
+            packed = idx;
+            if (idx != 255)
+                packed |= (int)atomicAdd(&T.cnt[idx], (uint32_t)((next_head - lane) * SC_PX)) << 8;
+        }
+        packed = __shfl(packed, first_lane);
+        if (whole) {
+            const int w0 = (packed & 255) == 255 ? 255 : packed + (((lane - first_lane) * SC_PX) << 8);
+#pragma unroll
+            for (int u = 0; u < SC_PX; ++u) where[u] = w0 == 255 ? 255 : w0 + (u << 8);
         } else {
-            T.base[tid] = L.offsets[gs] + atomicAdd(&L.cursor[gs], T.cnt[tid]);
-            T.end[tid] = L.ends[gs];
+#pragma unroll
+            for (int u = 0; u < SC_PX; ++u) {
+                const int c = cur[u];
+                const bool first_px = u == 0 || c != cur[u > 0 ? u - 1 : 0];
+                int w = -1;
+                if (c >= 0) {
+                    if (first_px) {
+                        const int idx = slot_of(c);
+                        w = idx;
+                        if (idx != 255) w |= (int)atomicAdd(&T.cnt[idx], (uint32_t)len_at[u]) << 8;
+                    } else {
+                        const int before = where[u > 0 ? u - 1 : 0];
+                        w = (before & 255) == 255 ? 255 : before + 256;
+                    }
+                }
+                where[u] = w;
+            }
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < SC_ROWS; ++u) {
-        const uint32_t xy = ((uint32_t)(y0 + u) << 16) | (uint32_t)x;
-        if (where[u] >= 0 && (where[u] & 255) != 255) {
-            if (!COUNT_ONLY) {
-                const int slot = where[u] & 255;
-                // 64-bit: the cursor of a label map that disagrees with the counts may run on
-                const unsigned long long dst = (unsigned long long)T.base[slot] + (uint32_t)(where[u] >> 8);
-                if (dst < T.end[slot]) L.sxy[dst] = xy;
+    // ---- the block's share of every label's run; where the shares start in the staging buffer
+    if (tid < SC_SLOTS) {
+        const bool used = T.key[tid] >= 0;
+        const uint32_t n = used ? T.cnt[tid] : 0u;
+        if (used) {
+            const size_t gs = (size_t)b * nseg + T.key[tid];
+            if (COUNT_ONLY) {
+                atomicAdd(&counts[gs], (int)n);
+            } else {
+                T.base[tid] = L.offsets[gs] + atomicAdd(&L.cursor[gs], n);
+                T.end[tid] = L.ends[gs];
             }
         }
-        // more labels in the block than table slots: these runs reserve their places one by one
-        int pending = (where[u] >= 0 && (where[u] & 255) == 255) ? lbl[u] : -1;
+        if (!COUNT_ONLY) {
+            uint32_t incl = n;                              // running sum over the wave's 64 slots
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                if (lane >= o) incl += up;
+            }
+            const unsigned long long usedm = __ballot(used);
+            if (wave == 0 && lane == 63) T.wave0_total = (int)incl, T.wave0_active = __popcll(usedm);
+            // (the second wave waits for the first one's totals at the barrier below)
+            T.off[tid] = incl - n;                          // wave 1: plus wave 0's total, added below
+            if (used) T.active[(wave == 0 ? 0 : 64) + __popcll(usedm & below)] = tid | (wave << 16);
+            if (wave == 1 && lane == 63) T.nactive = __popcll(usedm);
+        }
+    }
+    __syncthreads();
+    if (!COUNT_ONLY) {
+        // ---- stage the positions in (label, rank) order
+        const int add1 = T.wave0_total;
+#pragma unroll
+        for (int u = 0; u < SC_PX; ++u) {
+            const int w = where[u];
+            if (w >= 0 && (w & 255) != 255) {
+                const int slot = w & 255;
+                const uint32_t at = T.off[slot] + (slot >= 64 ? (uint32_t)add1 : 0u) + (uint32_t)(w >> 8);
+                if (at < (uint32_t)SC_BLOCK_PX) staged[at] = ((uint32_t)y << 16) | (uint32_t)(x0 + u);
+            }
+        }
+    }
+    __syncthreads();
+    if (!COUNT_ONLY) {
+        // ---- copy every label's share out, consecutive lanes on consecutive entries
+        const int n0 = T.wave0_active, n1 = T.nactive, add1 = T.wave0_total;
+        for (int k = 0; k < n0 + n1; ++k) {
+            const int slot = (k < n0 ? T.active[k] : T.active[64 + k - n0]) & 0xffff;
+            const uint32_t n = T.cnt[slot], from = T.off[slot] + (slot >= 64 ? (uint32_t)add1 : 0u);
+            const unsigned long long to = T.base[slot], end = T.end[slot];
+            for (uint32_t i = tid; i < n; i += SC_THREADS)
+                if (to + i < end && from + i < (uint32_t)SC_BLOCK_PX) L.sxy[to + i] = staged[from + i];
+        }
+    }
+    // ---- more labels in the block than table slots: these pixels reserve their places one by one
+#pragma unroll
+    for (int u = 0; u < SC_PX; ++u) {
+        const uint32_t xy = ((uint32_t)y << 16) | (uint32_t)(x0 + u);
+        int pending = (where[u] >= 0 && (where[u] & 255) == 255) ? cur[u] : -1;
         while (true) {
             const unsigned long long act = __ballot(pending >= 0);
             if (act == 0ull) break;
             const int leader = __ffsll((long long)act) - 1;
-            const int cur = __shfl(pending, leader);
-            const bool mine = pending == cur;
+            const int sel = __shfl(pending, leader);
+            const bool mine = pending == sel;
             const unsigned long long who = __ballot(mine);
-            const size_t gs = (size_t)b * nseg + cur;
+            const size_t gs = (size_t)b * nseg + sel;
             if (COUNT_ONLY) {
                 if (lane == leader) atomicAdd(&counts[gs], __popcll(who));
             } else {
@@ -1235,14 +1326,14 @@ extern "C" size_t imgan_dcd_list_bytes(int B, int H, int W, int nseg) {
 extern "C" int imgan_label_counts(const int32_t* labels, int B, int H, int W, int nseg,
                                   int32_t* counts, imgan_stream_t stream) {
     IMGAN_REQUIRE(labels && counts, "imgan_label_counts: null pointer");
-    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535 && H <= 65535 * SC_ROWS,
+    IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535 && H <= 65535 * SC_BLOCK_ROWS,
                   "imgan_label_counts: bad shape");
     IMGAN_REQUIRE((long long)H * W < 0x7fffffffLL, "imgan_label_counts: image too large");
     hipStream_t st = (hipStream_t)stream;
     IMGAN_HIP(hipMemsetAsync(counts, 0, (size_t)B * nseg * 4, st));
-    dim3 grid((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, SC_ROWS), (unsigned)B);
+    dim3 grid((unsigned)imgan::cdiv(W, SC_BLOCK_W), (unsigned)imgan::cdiv(H, SC_BLOCK_ROWS), (unsigned)B);
     SegLists none = {};
-    hipLaunchKernelGGL(seg_scatter_kernel<true>, grid, dim3(256), 0, st,
+    hipLaunchKernelGGL(seg_scatter_kernel<true>, grid, dim3(SC_THREADS), 0, st,
                        labels, B, H, W, nseg, none, counts);
     return imgan::check_launch("seg_scatter_kernel<count>");
 }
@@ -1282,8 +1373,8 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
     IMGAN_HIP(hipMemsetAsync(L.hdr, 0, 256, st));
     hipLaunchKernelGGL(seg_plan_kernel, dim3((unsigned)B), dim3(1024), 0, st, counts, bbox, nseg, H, W, L,
                        cap0, cap1, CAP_LARGE, n_big_out);
-    dim3 gsc((unsigned)imgan::cdiv(W, 256), (unsigned)imgan::cdiv(H, SC_ROWS), (unsigned)B);
-    hipLaunchKernelGGL(seg_scatter_kernel<false>, gsc, dim3(256), 0, st, labels, B, H, W, nseg, L,
+    dim3 gsc((unsigned)imgan::cdiv(W, SC_BLOCK_W), (unsigned)imgan::cdiv(H, SC_BLOCK_ROWS), (unsigned)B);
+    hipLaunchKernelGGL(seg_scatter_kernel<false>, gsc, dim3(SC_THREADS), 0, st, labels, B, H, W, nseg, L,
                        (int32_t*)nullptr);
     unsigned long long* stt = (unsigned long long*)stats;
     if (dedup) {
