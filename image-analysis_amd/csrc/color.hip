@@ -32,16 +32,35 @@ struct Lab3 {
     uint32_t L, a, b;
 };
 
+// a * b + c with 24-bit factors: one v_mad_i32_i24 (spelled out: left to itself the compiler turns a
+// chain of three into three multiplies and a three-input add)
+__device__ __forceinline__ int imad24(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));   // b: wave uniform
+    return r;
+}
+
 __device__ __forceinline__ Lab3 lab_px(const uint16_t* __restrict__ sg,
                                        const uint16_t* __restrict__ sc, uint32_t b8,
                                        uint32_t g8, uint32_t r8, const int* __restrict__ C) {
-    int R = sg[r8], G = sg[g8], B = sg[b8];
-    int fX = sc[(R * C[0] + G * C[1] + B * C[2] + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
-    int fY = sc[(R * C[3] + G * C[4] + B * C[5] + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
-    int fZ = sc[(R * C[6] + G * C[7] + B * C[8] + (1 << (LAB_SHIFT - 1))) >> LAB_SHIFT];
-    int L = (LSCALE * fY + LSHIFT + (1 << (LAB_SHIFT2 - 1))) >> LAB_SHIFT2;
-    int a = (500 * (fX - fY) + 128 * (1 << LAB_SHIFT2) + (1 << (LAB_SHIFT2 - 1))) >> LAB_SHIFT2;
-    int b = (200 * (fY - fZ) + 128 * (1 << LAB_SHIFT2) + (1 << (LAB_SHIFT2 - 1))) >> LAB_SHIFT2;
+    // gamma values and coefficients are below 2^13 (12-bit fixed point), the cube-root values below
+    // 2^16: 24-bit multiply-adds are exact here and a third of the instructions of the 32 / 64-bit
+    // forms the compiler picks for plain ints (it cannot see the ranges)
+    const int R = sg[r8], G = sg[g8], B = sg[b8];
+    const int half = 1 << (LAB_SHIFT - 1);
+    // table look-up at byte offset ((t >> 12) * 2) = (t >> 11) & ~1: a shift right and an AND are
+    // 2-cycle instructions, the shift left the compiler would use is a 4-cycle one
+    auto cbrt_at = [&](int t) {
+        uint32_t off = (uint32_t)t >> (LAB_SHIFT - 1);
+        asm("v_and_b32 %0, 0xfffffffe, %0" : "+v"(off));
+        return (int)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const unsigned char*>(sc) + off);
+    };
+    const int fX = cbrt_at(imad24(R, C[0], imad24(G, C[1], imad24(B, C[2], half))));
+    const int fY = cbrt_at(imad24(R, C[3], imad24(G, C[4], imad24(B, C[5], half))));
+    const int fZ = cbrt_at(imad24(R, C[6], imad24(G, C[7], imad24(B, C[8], half))));
+    int L = imad24(fY, LSCALE, LSHIFT + (1 << (LAB_SHIFT2 - 1))) >> LAB_SHIFT2;
+    int a = imad24(fX - fY, 500, 128 * (1 << LAB_SHIFT2) + (1 << (LAB_SHIFT2 - 1))) >> LAB_SHIFT2;
+    int b = imad24(fY - fZ, 200, 128 * (1 << LAB_SHIFT2) + (1 << (LAB_SHIFT2 - 1))) >> LAB_SHIFT2;
     // Keep the shift and the clamp apart: hipcc (ROCm 7.2) fuses "sat_u8(x >> 15)" pairs into
     // v_ashr_pk_u8_i32 and then assumes bits 31:16 of its result are zero; on gfx950 they are
     // not, which corrupted the neighbouring byte of the packed output.
