@@ -1377,6 +1377,10 @@ extern "C" int imgan_dcd_segments_listed(const uint8_t* lab, const int32_t* labe
     hipLaunchKernelGGL(seg_scatter_kernel<false>, gsc, dim3(SC_THREADS), 0, st, labels, B, H, W, nseg, L,
                        (int32_t*)nullptr);
     unsigned long long* stt = (unsigned long long*)stats;
+    // IMGAN_DCD_STOP_AFTER_SORT: leave after the sort pass, so that tools/check_lists.py can hold the
+    // lists against the label map
+    static const bool stop_after_sort = getenv("IMGAN_DCD_STOP_AFTER_SORT") != nullptr;
+    if (stop_after_sort) return imgan::check_launch("seg_scatter_kernel");
     if (dedup) {
         // the dedup tiers (dcd_tiers.hip), smallest first; what overflows every colour table ends
         // up on list 3 and takes the plain body here, one workgroup per CU

@@ -54,6 +54,17 @@ __device__ unsigned long long tier_timing[32];
         atomicAdd(&tier_timing[i], now_ - t_last_);                     \
         t_last_ = now_;                                                 \
     }
+#elif defined(IMGAN_TIER_PROGRESS)
+// debugging aid (tools/hang_watch.py; never built into the product): every workgroup's thread 0 leaves
+// {segment, phase} in host-visible memory
+__device__ volatile unsigned* tier_progress;
+#define TIER_MARK(i)                                                                      \
+    if (tid == 0 && tier_progress) {                                                      \
+        tier_progress[blockIdx.x * 4 + 0] = (unsigned)gs;                                 \
+        tier_progress[blockIdx.x * 4 + 1] = (unsigned)(i) | ((unsigned)CAP << 8);         \
+        tier_progress[blockIdx.x * 4 + 2] += 1u;                                          \
+        __threadfence_system();                                                           \
+    }
 #else
 #define TIER_MARK(i)
 #endif
@@ -104,7 +115,16 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     uint32_t* tab = reinterpret_cast<uint32_t*>(smem);     // hash table, then dense colour | cluster << 24
     uint16_t* ucnt = reinterpret_cast<uint16_t*>(tab + TU);
     uint16_t* idx = ucnt + TU;                             // per pixel: slot, then dense index
-    uint32_t* acc = reinterpret_cast<uint32_t*>(idx + CAP);
+    // The accumulators start where the plan's 6 bytes per pixel end -- NOT right behind idx: TU is
+    // rounded down to a multiple of 64, so table + counts + indices can be up to 256 bytes short of
+    // 6 CAP, and the coherence pass lays its 2-byte cell grid over everything up to 6 CAP
+    // (tier_fits in dcd_seg.hip: 2 area + 8 <= 6 CAP).  With the accumulators right behind idx a box
+    // of 21,377 .. 21,500 cells (CAP 7168) put its last parents on top of the first 128 entries of
+    // the join list, which lives in the accumulators' place: union-find walks over garbage, wrong
+    // coherence values or a workgroup that never comes back, depending on the order in which the
+    // join list was filled.
+    static_assert((size_t)TU * 6 + (size_t)CAP * 2 <= (size_t)CAP * 6, "the table does not fit its share");
+    uint32_t* acc = reinterpret_cast<uint32_t*>(smem + (size_t)CAP * 6);
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(acc + 2 * BUF);
     int* flags = reinterpret_cast<int*>(slots + KM);
     float* cen = reinterpret_cast<float*>(flags + 16);      // [cluster][component], written by wave 0
@@ -686,6 +706,13 @@ int launch(const TierArgs& A, size_t nsegs, int per_cu, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef IMGAN_TIER_PROGRESS
+extern "C" int imgan_debug_tier_progress(unsigned* host_visible) {
+    IMGAN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(tier_progress), &host_visible, sizeof(host_visible)));
+    return 0;
+}
+#endif
 
 #ifdef IMGAN_TIER_TIMING
 extern "C" int imgan_debug_tier_timing(unsigned long long* out32, int reset) {

@@ -279,6 +279,46 @@ def test_checkerboard_overflows_the_join_list():
         assert sorted(int(v) for v in w_stats[:, 7]) == [len(idx) // 2, (len(idx) + 1) // 2], s
 
 
+def test_cell_grid_up_to_the_tier_limit_keeps_clear_of_the_join_list():
+    """A sparse segment of the smallest tier whose bounding box has 146 x 147 = 21,462 cells: the
+    coherence pass's 2-byte cell grid then reaches within 76 bytes of the 6 x 7168 bytes the plan
+    allows (tier_fits: 2 area + 8 <= 6 CAP).  The colour table of that tier is 256 bytes shorter than
+    that (its slot count is rounded down), and the accumulators -- later the list of cells that need
+    an explicit union -- used to start right behind it: the last parents of such a box lay on top of
+    the first 128 entries of the list (wrong components, or a union-find walk that never ends).
+    Random membership gives ~800 list entries; lists, gather and the oracle must agree."""
+    torch = _torch()
+    from imgan import ops
+    from oracle import c_oracle
+    bw, bh, k = 146, 147, 2
+    H, W = bh + 5, bw + 7
+    rng = np.random.RandomState(11)
+    for trial in range(3):
+        member = rng.rand(bh, bw) < 0.32
+        member[0, 0] = member[0, -1] = member[-1, 0] = member[-1, -1] = True   # the box is the whole 146 x 147
+        member[-1, ::2] = True                                                 # members in the last row of cells
+        labels = np.full((H, W), -1, dtype=np.int32)
+        labels[3:3 + bh, 2:2 + bw][member] = 0
+        n = int(member.sum())
+        assert n <= 7168 and 2 * bw * bh > 6 * ((7168 * 2 // 3) // 64 * 64) + 2 * 7168
+        labf = rng.randint(0, 2, size=(H, W, 1)) * np.array([120, 10, 60]) + np.array([60, 120, 100])
+        labf = labf.astype(np.uint8)
+        lab = torch.from_numpy(labf).cuda().unsqueeze(0)
+        dl = torch.from_numpy(labels).cuda().unsqueeze(0)
+        idx = np.nonzero(labels.ravel() == 0)[0]
+        px = labf.reshape(-1, 3)[idx]
+        first = [int(np.nonzero((px == c).all(axis=1))[0][0]) for c in np.unique(px, axis=0)]
+        cen0 = px[first].astype(np.float32).reshape(1, 1, k, 3)
+        a = _run(ops, torch, lab, dl, 1, k, False, cen0=cen0)
+        for rep in range(4):                    # the list's order is a matter of timing
+            b = _run(ops, torch, lab, dl, 1, k, True, cen0=cen0)
+            _same(a, b)
+        rc = np.stack(np.divmod(idx, W), axis=1).astype(np.int32)
+        _, w_cen, w_stats, _ = c_oracle.dcd_segment(px, rc, np.array(first, dtype=np.int32))
+        assert np.array_equal(b[0][0, 0].view(np.uint32), w_cen.view(np.uint32)), trial
+        assert np.array_equal(b[2][0, 0].astype(np.uint64), w_stats), trial
+
+
 def test_step_outputs_do_not_depend_on_the_run():
     """The pixel lists come out in the order the sort pass's atomics land and the coherence pass
     unites cells lock-free: the results must not depend on either.  Three passes of the bench step
