@@ -9,6 +9,7 @@
 // fixed per thread and the sums in registers; CSD builds its 256-bin histogram in LDS
 // (privatised per workgroup) and flushes once.
 #include "common.h"
+#include "dcd_lists.h"
 #include "../../include/imgan.h"
 #include <math.h>
 #include <atomic>
@@ -618,10 +619,16 @@ __device__ unsigned long long rd_timing[16];
 #define RD_MARK(i)
 #endif
 
+// LISTED: the region's pixels come from its run of the pixel lists that imgan_dcd_segments_listed
+// leaves behind (positions y << 16 | x, dcd_lists.h) instead of from a scan of its bounding box
+// against the label map: a superpixel's box holds 2.2 cells per pixel of its own, and every staged
+// cell costs about as much as a member (address arithmetic, two loads, the ballots).
+template <bool LISTED>
 __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     const uint8_t* __restrict__ img, const int32_t* __restrict__ labels, const int32_t* __restrict__ bbox,
     int H, int W, int nseg, int nbins, HmmdTab T, unsigned long long* __restrict__ cld_sums,
-    int32_t* __restrict__ ehd_out, int32_t* __restrict__ csd_out, int32_t* __restrict__ too_big) {
+    int32_t* __restrict__ ehd_out, int32_t* __restrict__ csd_out, int32_t* __restrict__ too_big,
+    imgan_dcd::SegLists L) {
     // pool: first the grey levels of the box's cells (edge histogram), then, for the colour
     // structure, bitmaps over the cells: per colour of a pass its cells, then, in place, their
     // dilation along x.  member / fits: the region's cells, and the cells where an 8 x 8 window fits.
@@ -679,6 +686,72 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     // (the very last pixel of the batch is read one byte early so that the load stays in bounds).
     constexpr int GU = 4;
     const uint32_t last_p = b == (int)gridDim.y - 1 ? (uint32_t)H * (uint32_t)W - 1u : 0xffffffffu;
+    if (LISTED) {
+        // The run's positions and colours are asked for a batch ahead: the first batch before the
+        // bitmaps below are set up (two dependent loads per pixel and two workgroups per CU leave
+        // little else to hide their latency behind), each later one while the batch before it is
+        // worked through.
+        constexpr int LU = 6;
+        const uint32_t run_at = L.offsets[gs];
+        const int run_n = (int)min(min(L.ends[gs] - run_at, L.cursor[gs]), (uint32_t)RD_CAP);
+        const uint32_t last_entry = gridDim.y * (uint32_t)H * (uint32_t)W - 1u;   // of the whole list
+        uint32_t xy[LU], raw[LU], sh[LU];
+        auto fetch = [&](int i0) {
+#pragma unroll
+            for (int u = 0; u < LU; ++u)
+                xy[u] = L.sxy[min(run_at + (uint32_t)max(min(i0 + u * RD_THREADS + tid, run_n - 1), 0), last_entry)];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                // clamped into the image: the lists are the caller's scratch memory
+                const int xa = min((int)(xy[u] & 0xffffu), W - 1), ya = min((int)(xy[u] >> 16), H - 1);
+                const uint32_t p = (uint32_t)__mul24(ya, W) + (uint32_t)xa;
+                sh[u] = p == last_p ? 1u : 0u;
+                raw[u] = *reinterpret_cast<const u32_any*>(im + (p * 3u - sh[u]));
+            }
+        };
+        fetch(0);
+        // the cells where a window fits follow from the box alone; the members are set bit by bit
+        for (int i = tid; i < nwords; i += RD_THREADS) member[i] = 0ull;
+        for (int i0 = 0; i0 < area; i0 += RD_THREADS) {
+            const int i = i0 + tid;
+            const int ic = i < area ? i : area - 1;
+            const int y = quot_inv(ic, bw, inv_bw);
+            const int x = ic - __mul24(y, bw);
+            const unsigned long long fbits = __ballot(i < area && x + 8 <= bw && y + 8 <= bh);
+            if (lane == 0 && i < area) fits[i >> 6] = fbits;
+        }
+        __syncthreads();
+        uint32_t* m32 = reinterpret_cast<uint32_t*>(member);
+        for (int i0 = 0; i0 < run_n; i0 += RD_THREADS * LU) {
+            uint32_t cxy[LU], cv[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) cxy[u] = xy[u], cv[u] = raw[u] >> (8u * sh[u]);
+            if (i0 + RD_THREADS * LU < run_n) fetch(i0 + RD_THREADS * LU);
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int i = i0 + u * RD_THREADS + tid;
+                const int x = (int)(cxy[u] & 0xffffu) - x0, y = (int)(cxy[u] >> 16) - y0;
+                // (a position outside the box is not the region's as far as this pass goes: the
+                // scan of the box would not have met it either)
+                if (i < run_n && (unsigned)x < (unsigned)bw && (unsigned)y < (unsigned)bh) {
+                    const int cell = __mul24(y, bw) + x;
+                    const uint32_t v = cv[u];
+                    const uint32_t cb = v & 255u, cg = (v >> 8) & 255u, cr = (v >> 16) & 255u;
+                    gray[cell] = (uint8_t)gray_px(cb, cg, cr);
+                    const uint32_t c = (uint32_t)hmmd_cell_tab((int)cb, (int)cg, (int)cr, T, rcp2d, sub8);
+                    col[cell] = (uint8_t)c;
+                    if (!((present[c >> 5] >> (c & 31u)) & 1u)) atomicOr(&present[c >> 5], 1u << (c & 31u));
+                    const int blk = quot_inv(y * 8, bh, inv_bh) * 8 + quot_inv(x * 8, bw, inv_bw);
+                    uint32_t* t4 = tab + (lane & (RD_TABS - 1)) * RD_TAB_PITCH + blk * 4;
+                    atomicAdd(t4, cb);
+                    atomicAdd(t4 + 1, cg);
+                    atomicAdd(t4 + 2, cr);
+                    atomicAdd(t4 + 3, 1u);
+                    atomicOr(&m32[cell >> 5], 1u << (cell & 31));
+                }
+            }
+        }
+    } else
     for (int i0 = 0; i0 < area; i0 += RD_THREADS * GU) {
         int xx[GU], yy[GU], lbl[GU];
         uint32_t raw[GU], sh[GU];
@@ -807,6 +880,39 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
             // store per slot that occurs among them
             // (four words per wave and step: the two dependent table reads of a step overlap)
             constexpr int BU = 4;
+            if (LISTED) {
+                // one bit per pixel of the region's run: its cell in the bitmap of its colour's slot
+                // (the positions are read again: they are still in the cache)
+                const uint32_t run_at = L.offsets[gs];
+                const int run_n = (int)min(min(L.ends[gs] - run_at, L.cursor[gs]), (uint32_t)RD_CAP);
+                uint32_t* R32 = reinterpret_cast<uint32_t*>(Rb);
+                if (g0 == 0)
+                    for (int k = tid; k < nwords; k += RD_THREADS) Rb[k] = member[k];
+                for (int i0 = 0; i0 < run_n; i0 += RD_THREADS * BU) {
+                    uint32_t xy[BU];
+#pragma unroll
+                    for (int u = 0; u < BU; ++u)
+                        xy[u] = L.sxy[run_at + (uint32_t)min(i0 + u * RD_THREADS + tid, run_n - 1)];
+                    int cell[BU], rr[BU];
+#pragma unroll
+                    for (int u = 0; u < BU; ++u) {
+                        const int x = (int)(xy[u] & 0xffffu) - x0, y = (int)(xy[u] >> 16) - y0;
+                        const bool ok = i0 + u * RD_THREADS + tid < run_n && (unsigned)x < (unsigned)bw &&
+                                        (unsigned)y < (unsigned)bh;
+                        cell[u] = ok ? __mul24(y, bw) + x : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < BU; ++u) rr[u] = slot_of[col[max(cell[u], 0)]];
+#pragma unroll
+                    for (int u = 0; u < BU; ++u) {
+                        int sl = rr[u];
+                        if (sl == 0) sl = 256;               // slot 256 is stored as 0 in the byte table
+                        const int r = sl - g0;
+                        if (cell[u] >= 0 && r >= 0 && r < ng)
+                            atomicOr(&R32[(size_t)r * nwords * 2 + (cell[u] >> 5)], 1u << (cell[u] & 31));
+                    }
+                }
+            } else
             for (int i0 = 0; i0 < area; i0 += RD_THREADS * BU) {
                 int rr[BU];
                 bool mm[BU];
@@ -1119,11 +1225,11 @@ extern "C" size_t imgan_region_descriptors_scratch_bytes(int B, int nseg) {
     return B < 1 || nseg < 1 ? 0 : (size_t)B * nseg * 64 * 4 * 8;
 }
 
-extern "C" int imgan_region_descriptors(const uint8_t* bgr, const int32_t* labels, const int32_t* bbox,
-                                        int B, int H, int W, int nseg, int nbins, int32_t* cld_out,
-                                        int32_t* ehd_out, int32_t* csd_out, int32_t* too_big_out,
-                                        void* scratch, imgan_stream_t stream) {
-    IMGAN_REQUIRE(bgr && labels && bbox && cld_out && ehd_out && csd_out && too_big_out && scratch,
+static int region_descriptors(const uint8_t* bgr, const int32_t* labels, const int32_t* bbox,
+                              const void* list_scratch, int B, int H, int W, int nseg, int nbins,
+                              int32_t* cld_out, int32_t* ehd_out, int32_t* csd_out, int32_t* too_big_out,
+                              void* scratch, imgan_stream_t stream) {
+    IMGAN_REQUIRE(bgr && bbox && cld_out && ehd_out && csd_out && too_big_out && scratch,
                   "imgan_region_descriptors: null pointer");
     IMGAN_REQUIRE(B >= 1 && H >= 1 && W >= 1 && nseg >= 1 && B <= 65535,
                   "imgan_region_descriptors: bad shape");
@@ -1134,9 +1240,19 @@ extern "C" int imgan_region_descriptors(const uint8_t* bgr, const int32_t* label
     if (int rc = make_hmmd(nbins, &T)) return rc;
     hipStream_t st = (hipStream_t)stream;
     IMGAN_HIP(hipMemsetAsync(too_big_out, 0, 4, st));
-    hipLaunchKernelGGL(region_desc_kernel, dim3((unsigned)nseg, (unsigned)B), dim3(RD_THREADS), 0, st, bgr,
-                       labels, bbox, H, W, nseg, nbins, T, (unsigned long long*)scratch, ehd_out, csd_out,
-                       too_big_out);
+    if (list_scratch) {
+        IMGAN_REQUIRE(W <= 65536 && H <= 65535 && (long long)B * H * W < 0xffffffffLL,
+                      "imgan_region_descriptors_listed: the pixel lists hold 16-bit positions");
+        const imgan_dcd::SegLists L = imgan_dcd::bind_lists(const_cast<void*>(list_scratch), (size_t)B * nseg,
+                                                            (size_t)B * H * W);
+        hipLaunchKernelGGL(region_desc_kernel<true>, dim3((unsigned)nseg, (unsigned)B), dim3(RD_THREADS), 0, st,
+                           bgr, labels, bbox, H, W, nseg, nbins, T, (unsigned long long*)scratch, ehd_out,
+                           csd_out, too_big_out, L);
+    } else {
+        hipLaunchKernelGGL(region_desc_kernel<false>, dim3((unsigned)nseg, (unsigned)B), dim3(RD_THREADS), 0,
+                           st, bgr, labels, bbox, H, W, nseg, nbins, T, (unsigned long long*)scratch, ehd_out,
+                           csd_out, too_big_out, imgan_dcd::SegLists{});
+    }
     DctTable D;
     for (int i = 0; i < 8; ++i) {
         double s = i == 0 ? sqrt(0.125) : 0.5;
@@ -1145,6 +1261,25 @@ extern "C" int imgan_region_descriptors(const uint8_t* bgr, const int32_t* label
     hipLaunchKernelGGL(cld_finalise_kernel, dim3(B * nseg * 3), dim3(64), 0, st,
                        (const unsigned long long*)scratch, B * nseg, cld_out, D, 1);
     return imgan::check_launch("imgan_region_descriptors");
+}
+
+extern "C" int imgan_region_descriptors(const uint8_t* bgr, const int32_t* labels, const int32_t* bbox,
+                                        int B, int H, int W, int nseg, int nbins, int32_t* cld_out,
+                                        int32_t* ehd_out, int32_t* csd_out, int32_t* too_big_out,
+                                        void* scratch, imgan_stream_t stream) {
+    IMGAN_REQUIRE(labels, "imgan_region_descriptors: null pointer");
+    return region_descriptors(bgr, labels, bbox, nullptr, B, H, W, nseg, nbins, cld_out, ehd_out, csd_out,
+                              too_big_out, scratch, stream);
+}
+
+extern "C" int imgan_region_descriptors_listed(const uint8_t* bgr, const int32_t* bbox,
+                                               const void* list_scratch, int B, int H, int W, int nseg,
+                                               int nbins, int32_t* cld_out, int32_t* ehd_out,
+                                               int32_t* csd_out, int32_t* too_big_out, void* scratch,
+                                               imgan_stream_t stream) {
+    IMGAN_REQUIRE(list_scratch, "imgan_region_descriptors_listed: null pointer");
+    return region_descriptors(bgr, nullptr, bbox, list_scratch, B, H, W, nseg, nbins, cld_out, ehd_out,
+                              csd_out, too_big_out, scratch, stream);
 }
 
 static void make_dct(DctTable* D) {

@@ -104,6 +104,9 @@ SIGNATURES = {
     "imgan_region_descriptors_scratch_bytes": (c_size_t, [c_int, c_int]),
     "imgan_region_descriptors": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "imgan_region_descriptors_listed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p]),
     "imgan_region_descriptors_large_scratch_bytes": (c_size_t, [c_int, c_int]),
     "imgan_region_descriptors_large": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                                c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

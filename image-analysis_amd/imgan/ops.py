@@ -712,25 +712,35 @@ class RegionDescriptorPlan(object):
         self.scratch = torch.empty(max(lib.imgan_region_descriptors_scratch_bytes(self.B, self.nseg), 8),
                                    dtype=torch.uint8, device=dev)
 
-    def run(self, bgr, labels, bbox=None, large=False):
+    def run(self, bgr, labels, bbox=None, large=False, lists=None):
         """bbox: device buffer holding int32 [B,nseg,4] (e.g. the one the last SLIC round wrote);
         found with imgan_label_bbox when not given.  large: also finish the regions whose box is
-        too large for the on-chip pass (finish_large(); synchronises).  Returns (cld, ehd, csd)
-        device tensors."""
+        too large for the on-chip pass (finish_large(); synchronises).  lists: the list scratch of a
+        DcdPlan whose listed dominant-colour pass has just run on the same labels and boxes
+        (imgan_region_descriptors_listed: the regions' pixels come from their runs instead of a
+        scan of their boxes).  Returns (cld, ehd, csd) device tensors."""
         bgr = as_batch(_dev(bgr, torch.uint8, "bgr"))
         if labels.dim() == 2:
             labels = labels.unsqueeze(0)
         _dev(labels, torch.int32, "labels")
         if tuple(bgr.shape) != (self.B, self.H, self.W, 3) or tuple(labels.shape) != (self.B, self.H, self.W):
             raise ValueError("batch does not match the plan")
-        if bbox is None:
-            bbox = label_bbox(labels, self.nseg)
-        elif bbox.numel() * bbox.element_size() < self.B * self.nseg * 16:
+        if bbox is not None and bbox.numel() * bbox.element_size() < self.B * self.nseg * 16:
             raise ValueError("bbox buffer too small")
-        check(lib.imgan_region_descriptors(_ptr(bgr), _ptr(labels), _ptr(bbox), self.B, self.H, self.W,
-                                           self.nseg, self.nbins, _ptr(self.cld), _ptr(self.ehd),
-                                           _ptr(self.csd), _ptr(self.too_big), _ptr(self.scratch),
-                                           _stream()))
+        if lists is not None:
+            if bbox is None:
+                raise ValueError("the listed form needs the boxes the lists were made with")
+            check(lib.imgan_region_descriptors_listed(
+                _ptr(bgr), _ptr(bbox), _ptr(lists), self.B, self.H, self.W, self.nseg, self.nbins,
+                _ptr(self.cld), _ptr(self.ehd), _ptr(self.csd), _ptr(self.too_big), _ptr(self.scratch),
+                _stream()))
+        else:
+            if bbox is None:
+                bbox = label_bbox(labels, self.nseg)
+            check(lib.imgan_region_descriptors(_ptr(bgr), _ptr(labels), _ptr(bbox), self.B, self.H, self.W,
+                                               self.nseg, self.nbins, _ptr(self.cld), _ptr(self.ehd),
+                                               _ptr(self.csd), _ptr(self.too_big), _ptr(self.scratch),
+                                               _stream()))
         self._last = (bgr, labels, bbox)
         if large:
             self.finish_large()

@@ -6,6 +6,7 @@
 Everything runs in libimgan_hip.so on the current stream, with no host round trip.  The outputs are the
 fixed-width descriptor rows that the multi-GPU layout all-gathers (imgan.shard)."""
 import ctypes
+import os
 
 import torch
 
@@ -21,6 +22,8 @@ class FullPipeline(object):
         (configs[4]) instead of the whole image.  want_assign: also write the per-pixel
         dominant-colour index map (self.dcd.assign), which the descriptor rows do not need."""
         self.want_assign = bool(want_assign)
+        # IMGAN_REGION_BY_BOX=1: per-region descriptors by the scan of the boxes (for comparisons)
+        self.region_by_box = os.environ.get("IMGAN_REGION_BY_BOX") == "1"
         self.B, self.H, self.W = int(B), int(H), int(W)
         self.cw, self.num_iter, self.k = colour_weight, int(num_iter), int(dominant)
         self.seed, self.check_every, self.max_rounds = dcd_seed, dcd_check_every, dcd_max_rounds
@@ -96,10 +99,17 @@ class FullPipeline(object):
         Returns (image_rows int32 [B, 12+80+16+csd_bins+1], region_rows float32 [B, n*k*8])."""
         self.run_slic(bgr, timed)
         if self.per_region:
-            # rows per superpixel [B, n, 12+96+csd_bins+1]; the boxes are the last SLIC round's
+            # rows per superpixel [B, n, 12+96+csd_bins+1]; the boxes are the last SLIC round's.  The
+            # dominant colours go first: their sort pass leaves every superpixel's pixels as one run
+            # of positions, which the descriptor kernel walks instead of scanning the boxes
+            listed = bool(self.dcd.lists) and not self.region_by_box
+            if listed:
+                feats = self.run_dcd(timed)
             cld, ehd, csd = self._timed("region_desc", timed, lambda: self.region_desc.run(
-                bgr, self.slic.labels, bbox=self.dcd.bbox if self.boxed else None))
-            feats = self.run_dcd(timed)
+                bgr, self.slic.labels, bbox=self.dcd.bbox if (self.boxed or listed) else None,
+                lists=self.dcd.list_scratch if listed else None))
+            if not listed:
+                feats = self.run_dcd(timed)
             rows = torch.cat([cld[:, :, 0, :6], cld[:, :, 1, :3], cld[:, :, 2, :3], ehd, csd], dim=2)
             return rows.view(self.B, -1), feats.view(self.B, -1)
         cld = self._timed("cld", timed, lambda: self.desc.colour_layout(bgr))

@@ -356,6 +356,17 @@ int imgan_region_descriptors(const uint8_t* bgr, const int32_t* labels, const in
                              int32_t* csd_out, int32_t* too_big_out, void* scratch,
                              imgan_stream_t stream);
 
+/* imgan_region_descriptors with the regions' pixels taken from the pixel lists that
+ * imgan_dcd_segments_listed left in list_scratch for the SAME label map, boxes and shape (every
+ * region's positions as one contiguous run) instead of from a scan of every bounding box against
+ * the label map: a superpixel's box holds about 2.2 cells per pixel of its own.  Same outputs,
+ * same limits, bit for bit (no counterpart in the reference: it has no per-region form at all).
+ * The lists hold 16-bit positions: W <= 65536, H <= 65535, B * H * W < 2^32. */
+int imgan_region_descriptors_listed(const uint8_t* bgr, const int32_t* bbox, const void* list_scratch,
+                                    int B, int H, int W, int nseg, int nbins, int32_t* cld_out,
+                                    int32_t* ehd_out, int32_t* csd_out, int32_t* too_big_out,
+                                    void* scratch, imgan_stream_t stream);
+
 /* The same three descriptors of ONE region of ONE image whose bounding box is too large for the
  * on-chip pass above (MPEG7Descriptors is built on the merged regions, optigen_utils.py:46-49, whose
  * boxes reach the whole frame): streaming kernels over the box -- colour-layout block sums and the

@@ -370,6 +370,18 @@ def test_region_descriptors_odd_shapes_and_limits():
         assert np.array_equal(ehd[r], we), r
         assert np.array_equal(csd[r], ws), r
     assert csd[0, 256] > 0 and csd[1, 256] == 0 and ehd[3, 80:].sum() > 0
+    # the same rows from the pixel lists of a listed dominant-colour pass over the same map
+    # (imgan_region_descriptors_listed): bit for bit, the oversized region counted again
+    dcd = ops.DcdPlan(1, H, W, nseg, 2)
+    assert dcd.lists
+    ldev = torch.from_numpy(labels).cuda().unsqueeze(0)
+    cen = torch.empty((1, nseg, 2, 3), dtype=torch.float32, device="cuda")
+    dcd.kmeans(ops.bgr2lab(dev), ldev, cen, seed=3, max_rounds=2)
+    plan2 = ops.RegionDescriptorPlan(1, H, W, nseg)
+    cld2, ehd2, csd2 = plan2.run(dev, ldev, bbox=dcd.bbox, lists=dcd.list_scratch)
+    assert int(plan2.too_big.item()) == 1
+    assert np.array_equal(cld2.cpu().numpy()[0], cld) and np.array_equal(ehd2.cpu().numpy()[0], ehd)
+    assert np.array_equal(csd2.cpu().numpy()[0], csd)
 
 
 def test_large_cluster_centre_sums_integer_vs_float32():

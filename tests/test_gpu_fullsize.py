@@ -264,3 +264,10 @@ def test_mosaic_16k_superpixel_descriptors():
         assert np.array_equal(ehd[0, r].cpu().numpy(), np.concatenate([counts, nblk])), r
         h_, nw_ = M.region_colour_structure_counts(ci, cl, r)
         assert np.array_equal(csd[0, r].cpu().numpy(), np.concatenate([h_, [nw_]])), r
+    # ... and the listed form (the regions' pixels from the runs the dominant-colour pass left
+    # behind, as bench.py's configs[4] step takes them): all 49,729 rows bit for bit
+    rd2 = ops.RegionDescriptorPlan(B, H, W, n)
+    cld2, ehd2, csd2 = rd2.run(bgr, labels, bbox=dcd.bbox, lists=dcd.list_scratch)
+    torch.cuda.synchronize()
+    assert int(rd2.too_big.item()) == 0
+    assert torch.equal(cld2, cld) and torch.equal(ehd2, ehd) and torch.equal(csd2, csd)

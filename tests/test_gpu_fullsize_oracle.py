@@ -304,3 +304,10 @@ def test_region_descriptors_at_mosaic_geometry():
         checked += 1
     assert checked >= pipe.n - 2
     assert ehd[:, 80:].sum() > 0 and csd[:, 256].sum() > 0
+    # the step above took the regions' pixels from the dominant colours' pixel lists; the scan of
+    # the boxes against the label map (imgan_region_descriptors) gives the same rows
+    assert pipe.dcd.lists
+    pipe.region_desc.run(torch.from_numpy(img).cuda().unsqueeze(0), pipe.slic.labels, bbox=pipe.dcd.bbox)
+    assert np.array_equal(pipe.region_desc.cld[0].cpu().numpy(), cld)
+    assert np.array_equal(pipe.region_desc.ehd[0].cpu().numpy(), ehd)
+    assert np.array_equal(pipe.region_desc.csd[0].cpu().numpy(), csd)
