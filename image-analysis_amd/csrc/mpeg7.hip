@@ -359,24 +359,32 @@ __device__ __forceinline__ int hmmd_cell(int b, int g, int r, const HmmdTab& T) 
 
 // The same cell with its per-subspace constants and the reciprocals of the two divisors read from
 // LDS tables (region_desc_kernel: the selects from the argument arrays and the two reciprocals were
-// a third of this function's instructions).  rcp2d[d] = 1 / (2 d); sub8[sub] = {lo, nhue, nsum,
-// off, 2 (256 - lo), 1 / that as float bits, -, -}.
+// a third of this function's instructions).  rcp2d[d] = 1 / (2 d) with the subspace of d in its
+// three lowest mantissa bits (hmmd_rcp_entry; quot_inv corrects its estimate by +-1, which 2^-20
+// relative on a quotient below 720 cannot exceed -- the threshold loop over the argument arrays
+// was two scalar loops with a taken branch per step); sub8[sub] = {lo, nhue, nsum, off,
+// 2 (256 - lo), 1 / that as float bits, -, -}.
+__device__ __forceinline__ float hmmd_rcp_entry(int d, const HmmdTab& T) {
+    int sub = 0;
+    for (int i = 1; i < T.nsub; ++i) sub += (d >= T.thr[i]);
+    return __uint_as_float((__float_as_uint(1.0f / (float)(2 * max(d, 1))) & ~7u) | (uint32_t)sub);
+}
 __device__ __forceinline__ int hmmd_cell_tab(int b, int g, int r, const HmmdTab& T,
                                              const float* rcp2d, const int4* sub8) {
     const int mx = max(max(r, g), b), mn = min(min(r, g), b);
     const int d = mx - mn, s2 = mx + mn;
     int hue = 0;
+    const float inv2d = rcp2d[d];
     if (d > 0) {
         int num;
         if (r == mx) num = 60 * (g - b);
         else if (g == mx) num = 120 * d + 60 * (b - r);
         else num = 240 * d + 60 * (r - g);
         if (num < 0) num += 360 * d;
-        hue = quot_inv(2 * num + d, 2 * d, rcp2d[d]);
+        hue = quot_inv(2 * num + d, 2 * d, inv2d);
         if (hue >= 360) hue -= 360;
     }
-    int sub = 0;
-    for (int i = 1; i < T.nsub; ++i) sub += (d >= T.thr[i]);
+    const int sub = (int)(__float_as_uint(inv2d) & 7u);
     const int4 c0 = sub8[sub * 2], c1 = sub8[sub * 2 + 1];
     const int ihue = hue * c0.y / 360;
     const int isum = quot_inv((s2 - c0.x) * c0.z, c1.x, __int_as_float(c1.y));
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
     if (threadIdx.x == 0) held = 0;
     for (int i = threadIdx.x; i < CS_PH * 8 * CS_W / 4; i += 256)
         reinterpret_cast<uint4*>(runs)[i] = make_uint4(0, 0, 0, 0);
-    rcp2d[threadIdx.x] = 1.0f / (float)(2 * max((int)threadIdx.x, 1));
+    rcp2d[threadIdx.x] = hmmd_rcp_entry((int)threadIdx.x, T);
     if ((int)threadIdx.x < T.nsub) {
         const int lo = T.thr[threadIdx.x], den = 2 * (256 - lo);
         sub8[threadIdx.x * 2] = make_int4(lo, T.nhue[threadIdx.x], T.nsum[threadIdx.x], T.off[threadIdx.x]);
@@ -642,7 +650,9 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     __shared__ uint8_t slot_of[256], colour_of[257];
     __shared__ float rcp2d[256];
     __shared__ int4 sub8[5 * 2];
-    uint8_t* gray = reinterpret_cast<uint8_t*>(pool);
+    // edge histogram: one 64-bit word per block, {grey sums of its four quadrants, 10 bits each,
+    // number of the region's pixels in it << 40} (blocks of 2 x 2 or 4 x 4 cells at this capacity)
+    unsigned long long* eacc = pool;
     const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const size_t gs = (size_t)b * nseg + s;
     const int* bb = bbox + gs * 4;
@@ -664,11 +674,14 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
 #ifdef IMGAN_RD_TIMING
     unsigned long long t_last_ = wall_clock64();
 #endif
+    const int ebs = ehd_block_size_dev(bh, bw), elg = ebs >= 4 ? 2 : 1;   // 2 or 4 (RD_CAP / 1100 < 36)
+    const int nbx = bw >> elg, nby = bh >> elg;
+    for (int i = tid; i < nbx * nby; i += RD_THREADS) eacc[i] = 0ull;
     for (int i = tid; i < RD_TABS * RD_TAB_PITCH; i += RD_THREADS) tab[i] = 0;
     for (int i = tid; i < 256; i += RD_THREADS) hist[i] = 0;
     for (int i = tid; i < 96; i += RD_THREADS) ehd[i] = 0;
     if (tid < 8) present[tid] = 0;
-    if (tid < 256) rcp2d[tid] = 1.0f / (float)(2 * max(tid, 1));
+    if (tid < 256) rcp2d[tid] = hmmd_rcp_entry(tid, T);
     if (tid < T.nsub) {
         const int lo = T.thr[tid], den = 2 * (256 - lo);
         sub8[tid * 2] = make_int4(lo, T.nhue[tid], T.nsum[tid], T.off[tid]);
@@ -680,6 +693,13 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     const uint8_t* im = img + (size_t)b * H * W * 3;
     const int32_t* lab = labels + (size_t)b * H * W;
     const float inv_bw = 1.0f / (float)bw, inv_bh = 1.0f / (float)bh;
+    auto edge_add = [&](int x, int y, uint32_t g) {        // a pixel of the region at cell (x, y)
+        const int bx = x >> elg, by = y >> elg;
+        if (bx < nbx && by < nby) {
+            const int q = (((y >> (elg - 1)) & 1) << 1) | ((x >> (elg - 1)) & 1);
+            atomicAdd(&eacc[__mul24(by, nbx) + bx], ((unsigned long long)g << (10 * q)) + (1ull << 40));
+        }
+    };
     // Four cells per thread and step, every load issued before the first use (a step is bound by
     // the memory latency of its loads, not by their number); addresses are clamped into the box
     // instead of branched around, and the three colour bytes come with one unaligned dword load
@@ -737,7 +757,7 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
                     const int cell = __mul24(y, bw) + x;
                     const uint32_t v = cv[u];
                     const uint32_t cb = v & 255u, cg = (v >> 8) & 255u, cr = (v >> 16) & 255u;
-                    gray[cell] = (uint8_t)gray_px(cb, cg, cr);
+                    edge_add(x, y, gray_px(cb, cg, cr));
                     const uint32_t c = (uint32_t)hmmd_cell_tab((int)cb, (int)cg, (int)cr, T, rcp2d, sub8);
                     col[cell] = (uint8_t)c;
                     if (!((present[c >> 5] >> (c & 31u)) & 1u)) atomicOr(&present[c >> 5], 1u << (c & 31u));
@@ -776,9 +796,9 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
             const bool fit = live && xx[u] + 8 <= bw && yy[u] + 8 <= bh;
             const uint32_t v = raw[u] >> (8u * sh[u]);
             const uint32_t cb = v & 255u, cg = (v >> 8) & 255u, cr = (v >> 16) & 255u;
-            if (live) gray[i] = (uint8_t)gray_px(cb, cg, cr);
             int blk = -1;
             if (mem) {
+                edge_add(xx[u], yy[u], gray_px(cb, cg, cr));
                 const uint32_t c = (uint32_t)hmmd_cell_tab((int)cb, (int)cg, (int)cr, T, rcp2d, sub8);
                 col[i] = (uint8_t)c;
                 if (!((present[c >> 5] >> (c & 31u)) & 1u)) atomicOr(&present[c >> 5], 1u << (c & 31u));
@@ -808,26 +828,16 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
     auto is_member = [&](int cell) { return (member[cell >> 6] >> (cell & 63)) & 1ull; };
 
     // ---- edge histogram: blocks tile the box from its corner; a block votes if the region holds
-    // all of its pixels
+    // all of its pixels (its quadrant sums were added up pixel by pixel above)
     {
-        const int bs = ehd_block_size_dev(bh, bw), hb = bs >> 1;
-        const int nbx = bw / bs, nby = bh / bs;
+        const int hb = ebs >> 1;
         const float inv_nbx = 1.0f / (float)max(nbx, 1);
         for (int k = tid; k < nbx * nby; k += RD_THREADS) {
+            const unsigned long long w = eacc[k];
+            if ((int)(w >> 40) != ebs * ebs) continue;
             const int by = quot_inv(k, nbx, inv_nbx), bx = k - by * nbx;
-            int s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-            bool all = true;
-            for (int j = 0; j < bs; ++j)
-                for (int i = 0; i < bs; ++i) {
-                    const int cell = (by * bs + j) * bw + bx * bs + i;
-                    all = all && is_member(cell);
-                    const int g = gray[cell];
-                    s1 += (j < hb && i < hb) ? g : 0;
-                    s2 += (j < hb && i >= hb) ? g : 0;
-                    s3 += (j >= hb && i < hb) ? g : 0;
-                    s4 += (j >= hb && i >= hb) ? g : 0;
-                }
-            if (!all) continue;
+            const int s1 = (int)(w & 1023u), s2 = (int)((w >> 10) & 1023u), s3 = (int)((w >> 20) & 1023u),
+                      s4 = (int)((w >> 30) & 1023u);
             const int v = s1 - s2 + s3 - s4, h = s1 + s2 - s3 - s4, d45 = s1 - s4, d135 = s2 - s3,
                       nd = s1 - s2 - s3 + s4;
             const int e[5] = {v * v, h * h, 2 * d45 * d45, 2 * d135 * d135, 4 * nd * nd};
@@ -836,7 +846,7 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
 #pragma unroll
             for (int t = 1; t < 5; ++t)
                 if (e[t] > best) best = e[t], type = t;
-            const int sub = quot_inv(bx * bs * 4, bw, inv_bw) + quot_inv(by * bs * 4, bh, inv_bh) * 4;
+            const int sub = quot_inv(bx * ebs * 4, bw, inv_bw) + quot_inv(by * ebs * 4, bh, inv_bh) * 4;
             atomicAdd(&ehd[80 + sub], 1u);
             const int thr = 11 * hb * hb;
             if (best >= thr * thr) atomicAdd(&ehd[sub * 5 + type], 1u);
@@ -867,7 +877,7 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
         for (int w = 0; w < 8; ++w) nslots += __popc(present[w]);
         const int G = min(nslots, RD_POOL / nwords);           // >= 12
         const float inv_nw = 1.0f / (float)nwords;
-        __syncthreads();                                      // the edge histogram is done with `gray`
+        __syncthreads();                                      // the edge histogram is done with the pool
         RD_MARK(2)
         for (int g0 = 0; g0 < nslots; g0 += G) {
             const int ng = min(G, nslots - g0);
