@@ -28,6 +28,17 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
     return v;
 }
 
+// OR over the wave as a scalar: four DPP steps leave every row of 16 lanes with its own OR (no
+// LDS round trips, unlike the shuffles above), four lane reads join the rows
+__device__ __forceinline__ uint32_t wave_or_scalar(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);   // row_mirror
+    return (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) |
+                      __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
+}
+
 __device__ __forceinline__ uint32_t gray_px(uint32_t b, uint32_t g, uint32_t r) {
     return (4899u * r + 9617u * g + 1868u * b + 8192u) >> 14;
 }
@@ -457,6 +468,10 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
     __syncthreads();
     const int tu = threadIdx.x & 31;
     const int lane = threadIdx.x & 63;
+    // votes[w]: lane i holds the number of this wave's windows with colour 32 w + i (the counts are
+    // scalars -- one ballot per colour that occurs in the wave -- and ride in a lane of a vector
+    // register until the end; an LDS atomic per colour and trip cost twice the instructions)
+    int votes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int tv = threadIdx.x >> 5; tv < CS_H; tv += 8) {
         const bool valid = (u0 + tu < nwx) && (v0 + tv < nwy);
         uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -473,14 +488,20 @@ __global__ __launch_bounds__(256) void csd_kernel(const uint8_t* __restrict__ im
         // every colour present in a window counts once: count lanes per bit, one add per wave
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
-            uint32_t any = wave_or(m[w]);
+            if (__ballot(m[w] != 0u) == 0ull) continue;    // most words are empty
+            uint32_t any = wave_or_scalar(m[w]);
             while (any) {
-                int bit = __ffs((int)any) - 1;
+                const int bit = __ffs((int)any) - 1;
                 any &= any - 1;
-                unsigned long long vote = __ballot((m[w] >> bit) & 1u);
-                if (lane == 0) atomicAdd(&hist[w * 32 + bit], (uint32_t)__popcll(vote));
+                const unsigned long long vote = __ballot((m[w] & (1u << bit)) != 0u);
+                votes[w] += lane == bit ? (int)__popcll(vote) : 0;
             }
         }
+    }
+    if (lane < 32) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+            if (votes[w]) atomicAdd(&hist[w * 32 + lane], (uint32_t)votes[w]);
     }
     __syncthreads();
     int32_t* o = out + (size_t)b * (nbins + 1);
