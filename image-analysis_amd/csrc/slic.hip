@@ -953,10 +953,11 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                 hi += (v.x >> 16) + (v.y >> 16) + (v.z >> 16) + (v.w >> 16);
             }
         }
-        lo += __shfl_xor(lo, 1);
-        hi += __shfl_xor(hi, 1);
-        lo += __shfl_xor(lo, 2);
-        hi += __shfl_xor(hi, 2);
+        // lanes ^ 1 and ^ 2 by DPP quad permutations (a shuffle is an LDS round trip)
+        lo += (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0xb1, 0xf, 0xf, true);
+        hi += (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xb1, 0xf, 0xf, true);
+        lo += (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x4e, 0xf, 0xf, true);
+        hi += (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x4e, 0xf, 0xf, true);
         const uint32_t cnt = __shfl(hi, (lane & 48) + 4);      // row 1 of this slot: b | count
         if (live && q == 0 && cnt) {
             unsigned long long* dst = sums + (size_t)s_c[s].w * NFIELD;
@@ -991,13 +992,14 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                     }
                 }
             }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                xa = min(xa, __shfl_xor(xa, o));
-                ya = min(ya, __shfl_xor(ya, o));
-                xb = max(xb, __shfl_xor(xb, o));
-                yb = max(yb, __shfl_xor(yb, o));
-            }
+            // over the slot's 16 lanes = one DPP row: quad permutations, then the two mirrors
+#define ROW_STEP(ctrl)                                                                  \
+            xa = min(xa, __builtin_amdgcn_mov_dpp(xa, ctrl, 0xf, 0xf, true));           \
+            ya = min(ya, __builtin_amdgcn_mov_dpp(ya, ctrl, 0xf, 0xf, true));           \
+            xb = max(xb, __builtin_amdgcn_mov_dpp(xb, ctrl, 0xf, 0xf, true));           \
+            yb = max(yb, __builtin_amdgcn_mov_dpp(yb, ctrl, 0xf, 0xf, true));
+            ROW_STEP(0xb1) ROW_STEP(0x4e) ROW_STEP(0x141) ROW_STEP(0x140)
+#undef ROW_STEP
             if (s < macc && t16 == 0 && xb >= 0)
                 bbox_point_global(bbox + ((size_t)b * n + s_c[s].w) * 4, x0 + xa, y0 + ya, x0 + xb,
                                   y0 + yb);
