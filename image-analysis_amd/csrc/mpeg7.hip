@@ -292,6 +292,116 @@ __global__ __launch_bounds__(256) void ehd_sums_kernel(const uint8_t* __restrict
     for (int i = tid; i < nbx * 2; i += 256) Q[(i >> 1) * 4 + qy * 2 + (i & 1)] = ehd_tab[i];
 }
 
+// ---- colour layout sums and edge quadrant sums in ONE pass over the image (imgan_cld_ehd): both
+// walk strips of rows with the same four-columns-per-thread mapping, and each alone is bound by
+// reading the image.  A workgroup takes the rows of one quadrant half (hb = bs / 2 rows, as
+// ehd_sums_kernel; strips below the last edge block serve the colour layout alone).  A strip lies
+// in at most two rows of the 8 x 8 grid (the host checks hb * 8 <= H): the colour sums of the
+// rows above and below that boundary go to two LDS tables.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void cld_ehd_sums_kernel(const uint8_t* __restrict__ img, int H, int W,
+                                                           int bs, int nbx, int nby,
+                                                           unsigned long long* __restrict__ sums,
+                                                           uint32_t* __restrict__ qsum) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t ehd_tab[];
+    // colour sums in 16 copies (a lane adds to copy lane % 16): the 256 columns of a wave fall into
+    // two or three grid columns, and lanes that add to one LDS word take turns
+    constexpr int CE_COPIES = 16, CE_PITCH = 33;
+    __shared__ unsigned long long tab[2][CE_COPIES][CE_PITCH];
+    const int b = blockIdx.y, strip = blockIdx.x, hb = bs >> 1;
+    const int ya = strip * hb, yb = min(ya + hb, H);
+    const bool edge = strip < nby * 2;
+    const int by = strip >> 1, qy = strip & 1;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nbx * 2; i += 256) ehd_tab[i] = 0;
+    for (int i = tid; i < 2 * CE_COPIES * CE_PITCH; i += 256) (&tab[0][0][0])[i] = 0ull;
+    __syncthreads();
+    const int copy = tid & (CE_COPIES - 1);
+    const int gy0 = (int)(((long long)ya * 8) / H);
+    const int yc = min((int)((((long long)gy0 + 1) * H + 7) / 8), yb);   // first row of the next grid row
+    const uint8_t* im = img + (size_t)b * H * W * 3;
+    const int wuse = nbx * bs;                          // columns right of it belong to no edge block
+    const int nquad = (W + 3) / 4;
+    for (int q0 = 0; q0 < nquad; q0 += 256) {
+        const int x = (q0 + tid) * 4;
+        const bool live = x < W;
+        const int xl = live ? x : 0;
+        uint32_t g[4] = {0, 0, 0, 0};
+        for (int seg = 0; seg < 2; ++seg) {
+            const int ys = seg ? yc : ya, ye = seg ? yb : yc;
+            if (ys >= ye) continue;
+            uint32_t e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};     // B | R << 16 and G
+            int nrows = 0;
+            auto flush = [&]() {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (live && x + j < W) {
+                        const int gx = ((x + j) * 8) / W;
+                        unsigned long long* t4 = &tab[seg][copy][gx * 4];
+                        atomicAdd(t4, (unsigned long long)(e[j] & 0xffffu));
+                        atomicAdd(t4 + 1, (unsigned long long)o[j]);
+                        atomicAdd(t4 + 2, (unsigned long long)(e[j] >> 16));
+                        atomicAdd(t4 + 3, (unsigned long long)nrows);
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = o[j] = 0;
+                nrows = 0;
+            };
+            // four rows are asked for while the four before them are added up
+            uint32_t nxt[4][4];
+            auto fetch = [&](int y) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int yy = y + u < ye ? y + u : ye - 1;
+                    load_quad<ALIGNED>(im + (size_t)yy * W * 3, xl, W, y + u < ye ? 0xffffffffu : 0u, nxt[u]);
+                }
+            };
+            fetch(ys);
+            for (int y = ys; y < ye; y += 4) {
+                uint32_t px[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) px[u][j] = nxt[u][j];
+                if (y + 4 < ye) fetch(y + 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        e[j] += px[u][j] & 0xff00ffu;
+                        o[j] += (px[u][j] >> 8) & 0xffu;
+                        // (a masked pixel has gray 0)
+                        g[j] += gray_px(px[u][j] & 0xffu, (px[u][j] >> 8) & 0xffu, px[u][j] >> 16);
+                    }
+                nrows += min(4, ye - y);
+                if (nrows >= 252) flush();             // the 16-bit halves of e hold 257 rows
+            }
+            flush();
+        }
+        if (edge) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (live && x + j < wuse) {
+                    const int bx = (x + j) / bs;
+                    const int qx = (x + j - bx * bs) >= hb;
+                    atomicAdd(&ehd_tab[bx * 2 + qx], g[j]);
+                }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int seg = tid >> 5, gx = (tid >> 2) & 7, f = tid & 3;
+        unsigned long long v = 0;
+#pragma unroll
+        for (int c = 0; c < CE_COPIES; ++c) v += tab[seg][c][gx * 4 + f];
+        if (v) atomicAdd(&sums[((size_t)b * 64 + (gy0 + seg) * 8 + gx) * 4 + f], v);
+    }
+    if (edge) {
+        uint32_t* Q = qsum + ((size_t)b * nby + by) * nbx * 4;
+        for (int i = tid; i < nbx * 2; i += 256) Q[(i >> 1) * 4 + qy * 2 + (i & 1)] = ehd_tab[i];
+    }
+}
+
 __global__ void ehd_classify_kernel(const uint32_t* __restrict__ qsum, int B, int H, int W, int bs,
                                     int nbx, int nby, int threshold, int32_t* __restrict__ out) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1165,6 +1275,8 @@ extern "C" int imgan_cld_static(const uint8_t* bgr, int B, int H, int W, int32_t
     return cld_run(bgr, B, H, W, cld_out, ptr, (hipStream_t)stream, "imgan_cld_static");
 }
 
+static void make_dct(DctTable* D);
+
 static int ehd_block_size(int H, int W) {
     double temp = sqrt((double)W * H / 1100.0);
     int bs = (int)(temp / 2) * 2;
@@ -1207,6 +1319,43 @@ extern "C" int imgan_ehd(const uint8_t* bgr, int B, int H, int W, int32_t* ehd_o
     hipLaunchKernelGGL(ehd_classify_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st,
                        (const uint32_t*)scratch, B, H, W, bs, nbx, nby, 11, ehd_out);
     return imgan::check_launch("imgan_ehd");
+}
+
+// imgan_cld + imgan_ehd with one pass over the image for both sets of sums (same results: the sums
+// are integers).  Shapes where a strip of edge-block rows could span more than two rows of the
+// colour grid (aspect ratios beyond 60 : 1) or that hold no edge block take the two calls.
+extern "C" int imgan_cld_ehd(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out, int32_t* ehd_out,
+                             void* cld_scratch, void* ehd_scratch, imgan_stream_t stream) {
+    if (int rc = cld_check(bgr, B, H, W, cld_out)) return rc;
+    IMGAN_REQUIRE(ehd_out && cld_scratch && ehd_scratch, "imgan_cld_ehd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int bs = ehd_block_size(H, W), hb = bs / 2;
+    const int nbx = W / bs, nby = H / bs;
+    const size_t lds = (size_t)nbx * 2 * 4;
+    if (nbx == 0 || nby == 0 || (long long)hb * 8 > H || lds > 48 * 1024 ||
+        (double)hb * hb * 255.0 >= 4294967295.0) {
+        if (int rc = imgan_cld(bgr, B, H, W, cld_out, cld_scratch, stream)) return rc;
+        return imgan_ehd(bgr, B, H, W, ehd_out, ehd_scratch, stream);
+    }
+    unsigned long long* sums = (unsigned long long*)cld_scratch;
+    IMGAN_HIP(hipMemsetAsync(sums, 0, imgan_cld_scratch_bytes(B), st));
+    IMGAN_HIP(hipMemsetAsync(ehd_out, 0, (size_t)B * 96 * 4, st));
+    const int nstrips = nby * 2 + imgan::cdiv(H - nby * bs, hb);
+    dim3 grid((unsigned)nstrips, (unsigned)B);
+    if (W % 4 == 0 && ((uintptr_t)bgr & 3) == 0)
+        hipLaunchKernelGGL(cld_ehd_sums_kernel<true>, grid, dim3(256), lds, st, bgr, H, W, bs, nbx, nby, sums,
+                           (uint32_t*)ehd_scratch);
+    else
+        hipLaunchKernelGGL(cld_ehd_sums_kernel<false>, grid, dim3(256), lds, st, bgr, H, W, bs, nbx, nby, sums,
+                           (uint32_t*)ehd_scratch);
+    DctTable T;
+    make_dct(&T);
+    hipLaunchKernelGGL(cld_finalise_kernel, dim3(B * 3), dim3(64), 0, st, (const unsigned long long*)sums, B,
+                       cld_out, T, 0);
+    const int total = B * nbx * nby;
+    hipLaunchKernelGGL(ehd_classify_kernel, dim3(imgan::cdiv(total, 256)), dim3(256), 0, st,
+                       (const uint32_t*)ehd_scratch, B, H, W, bs, nbx, nby, 11, ehd_out);
+    return imgan::check_launch("imgan_cld_ehd");
 }
 
 extern "C" int imgan_hmmd_quantise(const uint8_t* bgr, uint8_t* out, int64_t npix, int nbins,

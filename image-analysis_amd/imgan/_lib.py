@@ -99,6 +99,7 @@ SIGNATURES = {
     "imgan_cld_static_prepare": (c_int, []),
     "imgan_ehd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "imgan_ehd_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "imgan_cld_ehd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "imgan_csd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "imgan_hmmd_quantise": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "imgan_region_descriptors_scratch_bytes": (c_size_t, [c_int, c_int]),

@@ -662,6 +662,14 @@ class DescriptorPlan(object):
                             _ptr(self.ehd_scratch), _stream()))
         return self.ehd
 
+    def colour_layout_and_edge_histogram(self, bgr):
+        """colour_layout() and edge_histogram() with one pass over the image for both
+        (imgan_cld_ehd); returns (cld, ehd)."""
+        bgr = self._img(bgr)
+        check(lib.imgan_cld_ehd(_ptr(bgr), self.B, self.H, self.W, _ptr(self.cld), _ptr(self.ehd),
+                                _ptr(self.cld_scratch), _ptr(self.ehd_scratch), _stream()))
+        return self.cld, self.ehd
+
     def colour_structure(self, bgr):
         bgr = self._img(bgr)
         check(lib.imgan_csd(_ptr(bgr), self.B, self.H, self.W, self.nbins, _ptr(self.csd),

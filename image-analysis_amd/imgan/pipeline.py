@@ -112,8 +112,7 @@ class FullPipeline(object):
                 feats = self.run_dcd(timed)
             rows = torch.cat([cld[:, :, 0, :6], cld[:, :, 1, :3], cld[:, :, 2, :3], ehd, csd], dim=2)
             return rows.view(self.B, -1), feats.view(self.B, -1)
-        cld = self._timed("cld", timed, lambda: self.desc.colour_layout(bgr))
-        ehd = self._timed("ehd", timed, lambda: self.desc.edge_histogram(bgr))
+        cld, ehd = self._timed("cld+ehd", timed, lambda: self.desc.colour_layout_and_edge_histogram(bgr))
         csd = self._timed("csd", timed, lambda: self.desc.colour_structure(bgr))
         feats = self.run_dcd(timed)
         image_rows = torch.cat([cld[:, 0, :6], cld[:, 1, :3], cld[:, 2, :3], ehd, csd], dim=1)

@@ -333,6 +333,12 @@ int imgan_cld_static_prepare(void);
 int imgan_ehd(const uint8_t* bgr, int B, int H, int W, int32_t* ehd_out, void* scratch,
               imgan_stream_t stream);
 size_t imgan_ehd_scratch_bytes(int B, int H, int W);
+/* imgan_cld and imgan_ehd in one call that reads the image once for both sets of sums (each of
+ * the two is bound by reading the image); same outputs bit for bit, same scratch buffers
+ * (cld_scratch: imgan_cld_scratch_bytes, ehd_scratch: imgan_ehd_scratch_bytes).  No counterpart in
+ * the reference (neither descriptor is in it); the batch pipeline's form of the two. */
+int imgan_cld_ehd(const uint8_t* bgr, int B, int H, int W, int32_t* cld_out, int32_t* ehd_out,
+                  void* cld_scratch, void* ehd_scratch, imgan_stream_t stream);
 int imgan_csd(const uint8_t* bgr, int B, int H, int W, int nbins, int32_t* csd_out,
               imgan_stream_t stream);
 int imgan_hmmd_quantise(const uint8_t* bgr, uint8_t* out, int64_t npix, int nbins,

@@ -172,6 +172,29 @@ def test_cld_ehd_csd_match_oracle(shape):
         assert np.array_equal(ehd[b, :80], counts) and np.array_equal(ehd[b, 80:], nblk)
         hist, nwin = M.colour_structure_counts(imgs[b])
         assert np.array_equal(csd[b, :256], hist) and csd[b, 256] == nwin
+    # the batch pipeline's form of the first two: one pass over the image for both (imgan_cld_ehd)
+    plan2 = ops.DescriptorPlan(3, H, W)
+    cld2, ehd2 = plan2.colour_layout_and_edge_histogram(dev)
+    assert np.array_equal(cld2.cpu().numpy(), cld) and np.array_equal(ehd2.cpu().numpy(), ehd)
+
+
+@pytest.mark.parametrize("shape", [(1080, 1920), (1050, 1573), (2160, 3840), (33, 4000), (600, 9)])
+def test_cld_ehd_one_pass_equals_the_two_calls(shape):
+    """imgan_cld_ehd against imgan_cld + imgan_ehd at the bench's sizes (edge blocks of 42 / 36 / 86
+    pixels, strips that straddle a row of the colour grid, rows below the last edge block), an
+    unaligned width, and two shapes so flat / so narrow that the call falls back to the two passes."""
+    torch = _torch()
+    from imgan import ops
+    H, W = shape
+    rng = np.random.RandomState(H + W)
+    img = torch.from_numpy(rng.randint(0, 256, (2, H, W, 3), dtype=np.uint8)).cuda()
+    plan = ops.DescriptorPlan(2, H, W)
+    cld = plan.colour_layout(img).clone()
+    ehd = plan.edge_histogram(img).clone()
+    plan2 = ops.DescriptorPlan(2, H, W)
+    cld2, ehd2 = plan2.colour_layout_and_edge_histogram(img)
+    assert torch.equal(cld2, cld) and torch.equal(ehd2, ehd)
+    assert int(ehd[:, 80:].sum()) > 0 or min(H, W) < 12
 
 
 @pytest.mark.parametrize("nbins", [32, 64, 128, 256])

@@ -37,8 +37,7 @@ for rep in range(2):
     if stage in ("dcd", "all"):
         pipe.run_dcd()
     if stage in ("desc", "all"):
-        pipe.desc.colour_layout(bgr)
-        pipe.desc.edge_histogram(bgr)
+        pipe.desc.colour_layout_and_edge_histogram(bgr)
         pipe.desc.colour_structure(bgr)
 torch.cuda.synchronize()
 print("done", stage, B)
