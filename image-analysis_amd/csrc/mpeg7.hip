@@ -82,14 +82,18 @@ constexpr int CLD_PARTS = 4;
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void cld_sums_kernel(const uint8_t* __restrict__ img, int H,
                                                        int W, unsigned long long* __restrict__ sums) {
-    __shared__ unsigned long long tab[8][4];
+    // 16 copies of the sums (a lane adds to copy lane % 16): the 256 columns of a wave fall into two
+    // or three grid columns, and lanes that add to one LDS word take turns
+    constexpr int COPIES = 16, PITCH = 33;
+    __shared__ unsigned long long tab[COPIES][PITCH];
     const int b = blockIdx.z, gy = blockIdx.y / CLD_PARTS, part = blockIdx.y % CLD_PARTS;
     const int r0 = (gy * H + 7) / 8, r1 = ((gy + 1) * H + 7) / 8;
     const int per = (r1 - r0 + CLD_PARTS - 1) / CLD_PARTS;
     const int ya = r0 + part * per, yb = min(ya + per, r1);
     const int tid = threadIdx.x;
-    if (tid < 32) tab[tid >> 2][tid & 3] = 0ull;
+    for (int i = tid; i < COPIES * PITCH; i += 256) (&tab[0][0])[i] = 0ull;
     __syncthreads();
+    const int copy = tid & (COPIES - 1);
     const uint8_t* im = img + (size_t)b * H * W * 3;
     const int nquad = (W + 3) / 4;
     for (int q0 = 0; q0 < nquad && ya < yb; q0 += 256) {
@@ -103,10 +107,11 @@ __global__ __launch_bounds__(256) void cld_sums_kernel(const uint8_t* __restrict
             for (int j = 0; j < 4; ++j)
                 if (live && x + j < W) {
                     const int gx = ((x + j) * 8) / W;
-                    atomicAdd(&tab[gx][0], (unsigned long long)(e[j] & 0xffffu));
-                    atomicAdd(&tab[gx][1], (unsigned long long)o[j]);
-                    atomicAdd(&tab[gx][2], (unsigned long long)(e[j] >> 16));
-                    atomicAdd(&tab[gx][3], (unsigned long long)nrows);
+                    unsigned long long* t4 = &tab[copy][gx * 4];
+                    atomicAdd(t4, (unsigned long long)(e[j] & 0xffffu));
+                    atomicAdd(t4 + 1, (unsigned long long)o[j]);
+                    atomicAdd(t4 + 2, (unsigned long long)(e[j] >> 16));
+                    atomicAdd(t4 + 3, (unsigned long long)nrows);
                 }
 #pragma unroll
             for (int j = 0; j < 4; ++j) e[j] = o[j] = 0;
@@ -133,8 +138,12 @@ __global__ __launch_bounds__(256) void cld_sums_kernel(const uint8_t* __restrict
         flush();
     }
     __syncthreads();
-    if (tid < 32 && tab[tid >> 2][tid & 3])
-        atomicAdd(&sums[((size_t)b * 64 + gy * 8 + (tid >> 2)) * 4 + (tid & 3)], tab[tid >> 2][tid & 3]);
+    if (tid < 32) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int c = 0; c < COPIES; ++c) v += tab[c][tid];
+        if (v) atomicAdd(&sums[((size_t)b * 64 + gy * 8 + (tid >> 2)) * 4 + (tid & 3)], v);
+    }
 }
 
 struct DctTable {
