@@ -540,10 +540,10 @@ def main():
                 note="largest share of the step time; timed around the C call, i.e. the sum of the five "
                      "kernels it launches back to back.  Algorithmic bytes = SURVEY 8d's streaming figure "
                      "8*T + 13*P B/px with T = %.1f measured Lloyd rounds per pixel, P = 1; the rounds run "
-                     "in LDS, so the HBM traffic it must move is 24 B/px (7 labels + Lab in, 8 list out, "
-                     "8 list in, 1 assignment out; traffic above that is the sort's partial lines) and "
-                     "the kernels are bound by the vector pipe (SQ_ACTIVE_INST_VALU x 4 / SIMDs / cycles = 0.90 "
-                     "on the small tier, profiles/r03_pmc_B64.txt)" % t_bar),
+                     "in LDS, so the HBM traffic it must move is 15 B/px (4 labels in, 4 positions out, "
+                     "4 positions + 3 colours in; traffic above that: partial lines of the sort pass and of the "
+                     "colour gather) and the kernels are bound by the vector pipe (SQ_ACTIVE_INST_VALU x 4 / "
+                     "SIMDs / cycles = 0.88 on the small tier, profiles/r03_pmc_B64.txt)" % t_bar),
             "roofline_kernels": others,
             "dcd_segments_at_round_cap": pipe.segments_at_round_cap(),
             "dcd_segments_left_to_streaming_rounds": int(segments_left),
