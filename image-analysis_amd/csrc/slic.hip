@@ -507,6 +507,11 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // 7 waves per SIMD: what the LDS of the common configurations allows (one workgroup = one wave
 // per SIMD); without the hint the compiler settles on 77 registers, one wave short of that
@@ -699,6 +704,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
 #pragma unroll
         for (int j = 0; j < R; ++j) slot[j] = -1;
         unsigned tied = 0;                  // bit j: the best key of pixel j may have been met again
+        int lowest = 0;                     // the lane's lowest slot: negative if one of its pixels has none
         if (MODE == 0) {
             // Issue costs measured on this chip (tools/issue_rate.hip, profiles/r03_issue_rate.txt): a
             // wave64 add / subtract / logic operation (v_bitop3 included) whose operands are vector
@@ -778,13 +784,19 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                 const int8v c = rec[1 + s];
                 eval(s, c, wy0 - c[1] + S, false);
             }
-            unsigned long long any_near = 0ull;
+            // one test for the lane's R rows: the smallest difference of the two lowest keys
+            uint32_t gap[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 slot[j] = best[j] & mbits;
-                any_near |= __builtin_amdgcn_ballot_w64((uint32_t)(best[j] ^ best2[j]) <= (uint32_t)mbits);
+                gap[j] = (uint32_t)(best[j] ^ best2[j]);
             }
-            if (any_near != 0ull) {                      // wave uniform
+            uint32_t least = gap[0];
+#pragma unroll
+            for (int j = 1; j + 1 < R; j += 2) least = umin3(least, gap[j], gap[j + 1]);
+            if ((R & 1) == 0) least = min(least, gap[R - 1]);
+            lowest = 0;                                  // every pixel has a slot unless the replay says otherwise
+            if (__builtin_amdgcn_ballot_w64(least <= (uint32_t)mbits) != 0ull) {   // wave uniform
                 ASSIGN_COUNT(4);
                 // Rows that hold a pixel whose two lowest keys agree above the slot bits (or a pixel
                 // no candidate covers: both still at their start value): the whole wave goes over
@@ -794,8 +806,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                 // float64 distances.
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    if (__builtin_amdgcn_ballot_w64((uint32_t)(best[j] ^ best2[j]) <= (uint32_t)mbits) == 0ull)
-                        continue;
+                    if (__builtin_amdgcn_ballot_w64(gap[j] <= (uint32_t)mbits) == 0ull) continue;
                     int kb = 0, sb = -1;
                     bool dup = false;
                     for (int s = 0; s < m; ++s) {
@@ -811,6 +822,8 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                     slot[j] = sb;
                     tied |= (dup && sb >= 0) ? (1u << j) : 0u;
                 }
+#pragma unroll
+                for (int j = 0; j < R; ++j) lowest = min(lowest, slot[j]);     // -1: a pixel no window covers
             }
         } else {
             typename KeyT<MODE>::type best[R];
@@ -864,9 +877,11 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
         // addresses are wave uniform (scalar base + lane offset); LDS offsets use 24-bit
         // multiplies (the 32-bit multiply-add of this chip is a quarter-rate 64-bit one).
         int32_t* rowp = labels + ((size_t)b * H + (y0 + wy0)) * W + x0;
-        int lowest = slot[0];
+        if (MODE != 0) {
+            lowest = slot[0];
 #pragma unroll
-        for (int j = 1; j < R; ++j) lowest = min(lowest, slot[j]);
+            for (int j = 1; j < R; ++j) lowest = min(lowest, slot[j]);
+        }
         const bool rows_full = y0 + wy0 + R <= H - 1;
         if (rows_full && m <= maxc && __builtin_amdgcn_ballot_w64(colok && lowest < 0) == 0ull) {
             ASSIGN_COUNT(0);
@@ -875,15 +890,27 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                 int lbl[R];
 #pragma unroll
                 for (int j = 0; j < R; ++j) lbl[j] = s_c[slot[j]].w;
+                // the stores: one scalar base for the R rows, the row's byte offset in a vector
+                // register (the compiler otherwise steps a 64-bit vector address from row to row)
+                {
+                    uint32_t off = (uint32_t)lane * 4u, row_bytes;
+                    asm("v_mov_b32 %0, %1" : "=v"(row_bytes) : "s"((uint32_t)W * 4u));
+                    char* const rows = reinterpret_cast<char*>(rowp);
 #pragma unroll
-                for (int j = 0; j < R; ++j) (rowp + (size_t)j * W)[lane] = lbl[j];
+                    for (int j = 0; j < R; ++j) {
+                        *reinterpret_cast<int32_t*>(rows + off) = lbl[j];
+                        off += row_bytes;
+                    }
+                }
+                uint32_t xy0 = (uint32_t)xr | ((uint32_t)wy0 << 16);
+                asm("" : "+v"(xy0));    // one register for the band: the row index is added as a literal
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     const uint32_t p = px[j];
                     uint32_t* a = acc + (__mul24(slot[j], 192) + lane);
-                    atomicAdd(a, __builtin_amdgcn_perm(0u, p, 0x0c010c00u));          // L | a << 16
-                    atomicAdd(a + 64, __builtin_amdgcn_perm(0x01u, p, 0x0c040c02u));  // b | 1 << 16
-                    atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)(wy0 + j) << 16));
+                    atomicAdd(a, p & 0x00ff00ffu);                                    // L | b << 16
+                    atomicAdd(a + 64, __builtin_amdgcn_perm(0x01u, p, 0x0c040c01u));  // a | 1 << 16
+                    atomicAdd(a + 128, xy0 + ((uint32_t)j << 16));
                 }
                 if (bbox) {
                     // one min / max pair per run of equal slots down the lane's rows (one run, as
@@ -913,8 +940,8 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
                     *lrow = s_c[slot[j]].w;
                     const uint32_t p = px[j];
                     uint32_t* a = acc + (__mul24(slot[j], 192) + lane);
-                    atomicAdd(a, (p & 0xffu) | ((p & 0xff00u) << 8));
-                    atomicAdd(a + 64, ((p >> 16) & 0xffu) | 0x10000u);
+                    atomicAdd(a, p & 0x00ff00ffu);
+                    atomicAdd(a + 64, ((p >> 8) & 0xffu) | 0x10000u);
                     atomicAdd(a + 128, (uint32_t)xr | ((uint32_t)yr << 16));
                     if (bbox) {
                         uint32_t* q = ybox + (__mul24(slot[j], 32) + (lane >> 2));
@@ -937,7 +964,7 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
     __syncthreads();
 
     // ---- reduce the 64 lane-private copies and flush: 16 lanes per slot = 4 lanes for each of
-    // its 3 packed rows (L|a, b|count, x'|y'), 16 copies per lane.  A copy holds at most
+    // its 3 packed rows (L|b, a|count, x'|y'), 16 copies per lane.  A copy holds at most
     // 4 waves x nsub bands x R rows = tile height <= 64 pixels, so its 16-bit halves cannot overflow
     // (64 * 255 < 65536); the halves are widened before they are summed.
     for (int s0 = 0; s0 < macc; s0 += 16) {
@@ -958,14 +985,14 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
         hi += (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0xb1, 0xf, 0xf, true);
         lo += (uint32_t)__builtin_amdgcn_mov_dpp((int)lo, 0x4e, 0xf, 0xf, true);
         hi += (uint32_t)__builtin_amdgcn_mov_dpp((int)hi, 0x4e, 0xf, 0xf, true);
-        const uint32_t cnt = __shfl(hi, (lane & 48) + 4);      // row 1 of this slot: b | count
+        const uint32_t cnt = __shfl(hi, (lane & 48) + 4);      // row 1 of this slot: a | count
         if (live && q == 0 && cnt) {
             unsigned long long* dst = sums + (size_t)s_c[s].w * NFIELD;
             if (r == 0) {
                 atomicAdd(&dst[0], (unsigned long long)lo);
-                atomicAdd(&dst[1], (unsigned long long)hi);
+                atomicAdd(&dst[2], (unsigned long long)hi);
             } else if (r == 1) {
-                atomicAdd(&dst[2], (unsigned long long)lo);
+                atomicAdd(&dst[1], (unsigned long long)lo);
                 atomicAdd(&dst[5], (unsigned long long)cnt);
             } else {
                 atomicAdd(&dst[3], (unsigned long long)lo + (unsigned long long)cnt * x0);
