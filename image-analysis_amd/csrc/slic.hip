@@ -666,7 +666,11 @@ __global__ __launch_bounds__(256) IMGAN_ASSIGN_WAVES void slic_assign_kernel(con
     const int twoS = 2 * S;
     const int nS2x2 = -2 * (int)P.S2;
     uint32_t* trw = tr + wave * (4 * 64);                // 4 rows at a time
-    for (int sub = 0; sub < nsub; ++sub) {
+    // unrolled over the (two) bands: which prefetched pixels a band uses is then fixed in the code
+    // instead of picked with selects (0.988 -> 0.983 ms)
+#pragma unroll
+    for (int sub = 0; sub < NSUBMAX; ++sub) {
+        if (sub >= nsub) break;
         const int wy0 = sub * BAND + wave * R;           // tile relative first row of this wave
         if (y0 + wy0 >= H - 1) continue;                 // whole wave below the image
         uint32_t px[R];
