@@ -510,10 +510,11 @@ def main():
                           traffic=pmc_traffic(key, "bgr2lab_kernel", npix)),
             roofline_line("csd_kernel", stage_ms["csd"], 3, npix, profile=prof,
                           traffic=pmc_traffic(key, "csd_kernel", npix)),
-            # colour layout and edge histogram share one pass over the image (imgan_cld_ehd): SURVEY
-            # 8d prices each at 3 B/px read
-            roofline_line("cld_ehd_sums_kernel (+finalise, classify)", stage_ms["cld+ehd"], 6, npix, profile=prof,
-                          traffic=pmc_traffic(key, "cld_ehd_sums_kernel", npix)),
+            # colour layout and edge histogram share one pass over the image (imgan_cld_ehd): priced
+            # with the 3 B/px the pass reads (SURVEY 8d prices each descriptor's read of the image, 6)
+            roofline_line("cld_ehd_sums_kernel (+finalise, classify)", stage_ms["cld+ehd"], 3, npix, profile=prof,
+                          traffic=pmc_traffic(key, "cld_ehd_sums_kernel", npix),
+                          note="one pass for both descriptors: 3 B/px read (two passes at 3 B/px each before)"),
         ]
         path_bytes_px = 6 + 63 + desc_bytes + dcd_survey
         out = {
