@@ -25,6 +25,18 @@ __device__ __forceinline__ uint32_t lab_at(const uint8_t* __restrict__ lab, size
     return *reinterpret_cast<const u32_unaligned*>(lab + gp * 3 - sh) >> (8u * sh);
 }
 
+// The same with 32-bit arithmetic, for images of less than 2^32 / 3 pixels: lab_img points at the
+// image's first byte (the same in every lane: a scalar base), last_off is the byte offset of the
+// batch's very last pixel when this is the last image, else 0xffffffff.  (The 64-bit form costs
+// eight 64-bit vector operations per pixel.)
+__device__ __forceinline__ uint32_t lab_at32(const uint8_t* __restrict__ lab_img, int x, int y, int H, int W,
+                                             uint32_t last_off) {
+    const uint32_t p = (uint32_t)(__mul24(min(max(y, 0), H - 1), W) + min(max(x, 0), W - 1));
+    const uint32_t off = p * 3u;
+    const uint32_t sh = off == last_off ? 1u : 0u;
+    return *reinterpret_cast<const u32_unaligned*>(lab_img + (off - sh)) >> (8u * sh);
+}
+
 // Capacity tiers (pixels a workgroup holds in LDS at 6 B each, and its thread count).
 // 768 threads = 3 waves on each SIMD of the CU per workgroup, 6 with the second workgroup: measured
 // against 512 / 640 / 896 / 1024 threads (5.6 / 6.3 / 8.0 / 7.4 ms where this takes 5.1): the

@@ -168,6 +168,9 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     const int area = bw * bh;
     const size_t img = (size_t)b * H * W;
     const int n = (int)min(run_n, (uint32_t)CAP);
+    // the segment's run: one scalar base, 32-bit indices below CAP (indexing the whole list takes
+    // 64-bit vector arithmetic per access)
+    const uint32_t* __restrict__ run = L.sxy + run_at;
 #ifdef IMGAN_TIER_TIMING
     unsigned long long t_last_ = wall_clock64();
     if (tid == 0) atomicAdd(&tier_timing[31], 1ull);
@@ -185,16 +188,26 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     {
         const bool kpow2 = (k & (k - 1)) == 0;
         constexpr int LU = 4;                              // loads in flight per thread
+        // 32-bit offsets from the image's first byte where the image allows them
+        const bool narrow = (unsigned long long)H * (unsigned long long)W * 3ull < 0xffffffffull;
+        const uint8_t* lab_img = A.lab + img * 3;
+        const uint32_t last_off = b == A.B - 1 ? ((uint32_t)H * (uint32_t)W - 1u) * 3u : 0xffffffffu;
         for (int i0 = 0; i0 < n; i0 += THREADS * LU) {
             // a table that has been given up is not worth the rest of the run
             if (*reinterpret_cast<volatile int*>(&s_full)) break;
             uint32_t v[LU], xy[LU];
 #pragma unroll
-            for (int u = 0; u < LU; ++u) xy[u] = L.sxy[run_at + min(i0 + u * THREADS + tid, n - 1)];
+            for (int u = 0; u < LU; ++u) xy[u] = run[min(i0 + u * THREADS + tid, n - 1)];
+            if (narrow) {                                  // the colours, by position
 #pragma unroll
-            for (int u = 0; u < LU; ++u)                   // the colours, by position
-                v[u] = lab_at(A.lab, img, (int)(xy[u] & 0xffffu), (int)(xy[u] >> 16), H, W,
-                              (size_t)A.B * H * W - 1);
+                for (int u = 0; u < LU; ++u)
+                    v[u] = lab_at32(lab_img, (int)(xy[u] & 0xffffu), (int)(xy[u] >> 16), H, W, last_off);
+            } else {
+#pragma unroll
+                for (int u = 0; u < LU; ++u)
+                    v[u] = lab_at(A.lab, img, (int)(xy[u] & 0xffffu), (int)(xy[u] >> 16), H, W,
+                                  (size_t)A.B * H * W - 1);
+            }
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
                 const int i = i0 + u * THREADS + tid;
@@ -480,7 +493,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
                 m &= m - 1;
                 unsigned long long best = ~0ull;
                 for (int i = tid; i < n; i += THREADS) {
-                    const uint32_t xy = L.sxy[run_at + i];
+                    const uint32_t xy = run[i];
                     const int x = min(max((int)(xy & 0xffffu), xmin), xmax);
                     const int y = min(max((int)(xy >> 16), ymin), ymax);
                     const unsigned long long key = resample_key((uint32_t)(y * W + x), A.seed, j);
@@ -513,7 +526,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     static_assert(NPT * THREADS == CAP, "CAP must be a multiple of the block size");
     uint32_t where[NPT];
 #pragma unroll
-    for (int t = 0; t < NPT; ++t) where[t] = L.sxy[run_at + min(tid + t * THREADS, n - 1)];
+    for (int t = 0; t < NPT; ++t) where[t] = run[min(tid + t * THREADS, n - 1)];
 
     // ---- statistics (:110-116): counts and sums are the last round's, the squares need a pass
     // over the distinct colours, weighted (a copy's sums stay below n * 255^2 < 2^32)

@@ -854,12 +854,15 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
         constexpr int LU = 6;
         const uint32_t run_at = L.offsets[gs];
         const int run_n = (int)min(min(L.ends[gs] - run_at, L.cursor[gs]), (uint32_t)RD_CAP);
+        // one scalar base for the run (kept inside the list even for a region without entries),
+        // 32-bit indices below RD_CAP
         const uint32_t last_entry = gridDim.y * (uint32_t)H * (uint32_t)W - 1u;   // of the whole list
+        const uint32_t* __restrict__ run = L.sxy + min(run_at, last_entry);
         uint32_t xy[LU], raw[LU], sh[LU];
         auto fetch = [&](int i0) {
 #pragma unroll
             for (int u = 0; u < LU; ++u)
-                xy[u] = L.sxy[min(run_at + (uint32_t)max(min(i0 + u * RD_THREADS + tid, run_n - 1), 0), last_entry)];
+                xy[u] = run[max(min(i0 + u * RD_THREADS + tid, run_n - 1), 0)];
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
                 // clamped into the image: the lists are the caller's scratch memory
@@ -1035,6 +1038,8 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
                 // (the positions are read again: they are still in the cache)
                 const uint32_t run_at = L.offsets[gs];
                 const int run_n = (int)min(min(L.ends[gs] - run_at, L.cursor[gs]), (uint32_t)RD_CAP);
+                const uint32_t* __restrict__ run2 =
+                    L.sxy + min(run_at, gridDim.y * (uint32_t)H * (uint32_t)W - 1u);
                 uint32_t* R32 = reinterpret_cast<uint32_t*>(Rb);
                 if (g0 == 0)
                     for (int k = tid; k < nwords; k += RD_THREADS) Rb[k] = member[k];
@@ -1042,7 +1047,7 @@ __global__ __launch_bounds__(RD_THREADS) void region_desc_kernel(
                     uint32_t xy[BU];
 #pragma unroll
                     for (int u = 0; u < BU; ++u)
-                        xy[u] = L.sxy[run_at + (uint32_t)min(i0 + u * RD_THREADS + tid, run_n - 1)];
+                        xy[u] = run2[min(i0 + u * RD_THREADS + tid, run_n - 1)];
                     int cell[BU], rr[BU];
 #pragma unroll
                     for (int u = 0; u < BU; ++u) {
