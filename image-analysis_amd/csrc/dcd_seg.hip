@@ -201,7 +201,9 @@ __global__ __launch_bounds__(1024) void seg_plan_kernel(const int32_t* __restric
             const int xmin = max(bb[0], 0), ymin = max(bb[1], 0);
             const int xmax = min(bb[2], W - 1), ymax = min(bb[3], H - 1);
             const bool empty = xmax < xmin || ymax < ymin || n == 0;
-            const long long area = empty ? 0 : (long long)(xmax - xmin + 1) * (ymax - ymin + 1);
+            // (the grid of the coherence pass: the box with a border of one cell on three sides --
+            // dcd_tiers.hip lays it out that way, the plain body uses the box alone)
+            const long long area = empty ? 0 : (long long)(xmax - xmin + 3) * (ymax - ymin + 2);
             const int t = tier_fits(n, area, cap0) ? 0 : tier_fits(n, area, cap1) ? 1
                           : tier_fits(n, area, cap2) ? 2 : 3;
             // place on its tier's list, for the moment relative to this image's share of it

@@ -165,7 +165,11 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
         return;
     }
     const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
-    const int area = bw * bh;
+    // The grid of the coherence pass is the box with a border of one cell above, left and right (its
+    // cells never hold a cluster): a cell's four earlier neighbours are then four plain reads, with
+    // no test for the box's edges (seg_plan_kernel sizes the tiers for the padded grid).
+    const int pw = bw + 2;
+    const int area = pw * (bh + 1);
     const size_t img = (size_t)b * H * W;
     const int n = (int)min(run_n, (uint32_t)CAP);
     // the segment's run: one scalar base, 32-bit indices below CAP (indexing the whole list takes
@@ -573,10 +577,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             const int x = min(max((int)(xy & 0xffffu), xmin), xmax);
             const int y = min(max((int)(xy >> 16), ymin), ymax);
             const uint32_t cl = tab[idx[i]] >> 24;
-            // bits 29-31: the cell has a row above / a column to its left / to its right in the box
-            const uint32_t edges = (y > ymin ? 0x20000000u : 0u) | (x > xmin ? 0x40000000u : 0u) |
-                                   (x < xmax ? 0x80000000u : 0u);
-            keep[t] = (uint32_t)(__mul24(y - ymin, bw) + (x - xmin)) | (cl << 16) | edges;
+            keep[t] = (uint32_t)(__mul24(y - ymin + 1, pw) + (x - xmin + 1)) | (cl << 16);
             if (A.assign) A.assign[img + (size_t)(uint32_t)(__mul24(y, W) + x)] = (uint8_t)cl;
         }
     }
@@ -604,20 +605,20 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     // neighbours' own links, and W covers NW; what is left is NE next to a missing N, which is
     // united explicitly below.  Those cells go on a list that the whole block works through evenly.
     // (Bit 25: no room on the list.)
+    // (no branch per pixel: a thread without a pixel in this slot reads the grid's first cells and
+    // compares them with a cluster nothing has; the four reads of a pixel are asked for together)
 #pragma unroll
     for (int t = 0; t < NPT; ++t) {
-        bool join = false;
-        if (keep[t] != 0xffffffffu) {
-            const uint32_t cell = keep[t] & 0xffffu;
-            const uint8_t c = (uint8_t)(keep[t] >> 16);
-            const bool up = (keep[t] >> 29) & 1u, lf = (keep[t] >> 30) & 1u, rt = keep[t] >> 31;
-            const bool n_ = up && cls[cell - bw] == c, w_ = lf && cls[cell - 1] == c;
-            const bool nw = up && lf && cls[cell - bw - 1] == c;
-            const bool ne = up && rt && cls[cell - bw + 1] == c;
-            // bits 26-28: 0 self, 1 N, 2 W, 3 NW, 4 NE
-            keep[t] |= (n_ ? 1u : w_ ? 2u : nw ? 3u : ne ? 4u : 0u) << 26;
-            join = !n_ && (w_ || nw) && ne;
-        }
+        const bool valid = keep[t] != 0xffffffffu;
+        const uint32_t cell = valid ? keep[t] & 0xffffu : (uint32_t)(pw + 1);
+        const uint32_t c = valid ? (keep[t] >> 16) & 0xffu : 0xfeu;
+        const uint8_t* above = cls + (cell - (uint32_t)pw - 1u);
+        const uint32_t vnw = above[0], vn = above[1], vne = above[2], vw = cls[cell - 1u];
+        const bool n_ = vn == c, w_ = vw == c, nw = vnw == c, ne = vne == c;
+        // bits 26-28: 0 self, 1 N, 2 W, 3 NW, 4 NE
+        const uint32_t dir = n_ ? 1u : w_ ? 2u : nw ? 3u : ne ? 4u : 0u;
+        if (valid) keep[t] |= dir << 26;
+        const bool join = !n_ & (w_ | nw) & ne;
         if (join) {
             const int at = atomicAdd(&s_joins, 1);
             if (at < JOINS)
@@ -632,22 +633,22 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     for (int t = 0; t < NPT; ++t)
         if (keep[t] != 0xffffffffu) {
             const uint32_t cell = keep[t] & 0xffffu, dir = (keep[t] >> 26) & 7u;
-            const uint32_t link = dir == 1u ? cell - bw : dir == 2u ? cell - 1 : dir == 3u ? cell - bw - 1
-                                                        : dir == 4u ? cell - bw + 1 : cell;
+            const uint32_t link = dir == 1u ? cell - pw : dir == 2u ? cell - 1 : dir == 3u ? cell - pw - 1
+                                                        : dir == 4u ? cell - pw + 1 : cell;
             par[cell] = (uint16_t)link;
         }
     __syncthreads();
     TIER_MARK(12)
     for (int e = tid, ne_ = min(s_joins, JOINS); e < ne_; e += THREADS) {
         const uint32_t cell = joins[e];
-        unite16(par, cell, cell - bw + 1);
+        unite16(par, cell, cell - pw + 1);
     }
     if (s_joins > JOINS) {
 #pragma unroll
         for (int t = 0; t < NPT; ++t)
             if (keep[t] != 0xffffffffu && (keep[t] & 0x2000000u)) {
                 const uint32_t cell = keep[t] & 0xffffu;
-                unite16(par, cell, cell - bw + 1);
+                unite16(par, cell, cell - pw + 1);
             }
     }
     __syncthreads();

@@ -280,9 +280,10 @@ def test_checkerboard_overflows_the_join_list():
 
 
 def test_cell_grid_up_to_the_tier_limit_keeps_clear_of_the_join_list():
-    """A sparse segment of the smallest tier whose bounding box has 146 x 147 = 21,462 cells: the
-    coherence pass's 2-byte cell grid then reaches within 76 bytes of the 6 x 7168 bytes the plan
-    allows (tier_fits: 2 area + 8 <= 6 CAP).  The colour table of that tier is 256 bytes shorter than
+    """A sparse segment of the smallest tier whose bounding box has 143 x 147 cells: with its border
+    (one cell above, left and right) the coherence pass's 2-byte cell grid has 145 x 148 = 21,460
+    cells and reaches within 80 bytes of the 6 x 7168 bytes the plan allows (tier_fits: 2 area + 8
+    <= 6 CAP).  The colour table of that tier is 256 bytes shorter than
     that (its slot count is rounded down), and the accumulators -- later the list of cells that need
     an explicit union -- used to start right behind it: the last parents of such a box lay on top of
     the first 128 entries of the list (wrong components, or a union-find walk that never ends).
@@ -290,17 +291,18 @@ def test_cell_grid_up_to_the_tier_limit_keeps_clear_of_the_join_list():
     torch = _torch()
     from imgan import ops
     from oracle import c_oracle
-    bw, bh, k = 146, 147, 2
+    bw, bh, k = 143, 147, 2
     H, W = bh + 5, bw + 7
     rng = np.random.RandomState(11)
     for trial in range(3):
         member = rng.rand(bh, bw) < 0.32
-        member[0, 0] = member[0, -1] = member[-1, 0] = member[-1, -1] = True   # the box is the whole 146 x 147
+        member[0, 0] = member[0, -1] = member[-1, 0] = member[-1, -1] = True   # the box is the whole 143 x 147
         member[-1, ::2] = True                                                 # members in the last row of cells
         labels = np.full((H, W), -1, dtype=np.int32)
         labels[3:3 + bh, 2:2 + bw][member] = 0
         n = int(member.sum())
-        assert n <= 7168 and 2 * bw * bh > 6 * ((7168 * 2 // 3) // 64 * 64) + 2 * 7168
+        grid = (bw + 2) * (bh + 1)
+        assert n <= 7168 and 2 * grid + 8 <= 6 * 7168 and 2 * grid > 6 * ((7168 * 2 // 3) // 64 * 64) + 2 * 7168
         labf = rng.randint(0, 2, size=(H, W, 1)) * np.array([120, 10, 60]) + np.array([60, 120, 100])
         labf = labf.astype(np.uint8)
         lab = torch.from_numpy(labf).cuda().unsqueeze(0)
