@@ -567,19 +567,26 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     // positions come from the list again --; the table's place is then reused as a grid over the
     // box: first the cluster of every cell (u8), from which each cell picks its link (kept in its
     // register as a direction), then, in the same place, the parents (u16).
+    // (the two table reads of a pixel are not branched around: all of a thread's reads of a kind
+    // are asked for together, a slot beyond the run repeats the run's last pixel and is dropped)
     uint32_t keep[NPT];
+    constexpr int KG = NPT % 7 == 0 ? 7 : NPT % 5 == 0 ? 5 : NPT % 4 == 0 ? 4 : 1;   // pixels per group of reads
 #pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int i = tid + t * THREADS;
-        keep[t] = 0xffffffffu;
-        if (i < n) {
-            const uint32_t xy = where[t];
+    for (int t0 = 0; t0 < NPT; t0 += KG) {
+#pragma unroll
+        for (int t = t0; t < t0 + KG; ++t) keep[t] = idx[min(tid + t * THREADS, n - 1)];
+#pragma unroll
+        for (int t = t0; t < t0 + KG; ++t) keep[t] = reinterpret_cast<const uint8_t*>(tab)[keep[t] * 4u + 3u];
+#pragma unroll
+        for (int t = t0; t < t0 + KG; ++t) {
+            const uint32_t xy = where[t], cl = keep[t];
             const int x = min(max((int)(xy & 0xffffu), xmin), xmax);
             const int y = min(max((int)(xy >> 16), ymin), ymax);
-            const uint32_t cl = tab[idx[i]] >> 24;
-            keep[t] = (uint32_t)(__mul24(y - ymin + 1, pw) + (x - xmin + 1)) | (cl << 16);
-            if (A.assign) A.assign[img + (size_t)(uint32_t)(__mul24(y, W) + x)] = (uint8_t)cl;
+            const bool valid = tid + t * THREADS < n;
+            keep[t] = valid ? (uint32_t)(__mul24(y - ymin + 1, pw) + (x - xmin + 1)) | (cl << 16) : 0xffffffffu;
+            if (A.assign && valid) A.assign[img + (size_t)(uint32_t)(__mul24(y, W) + x)] = (uint8_t)cl;
         }
+        __builtin_amdgcn_sched_barrier(0);                 // (keeps the groups apart: registers)
     }
     TIER_MARK(7)
     uint16_t* par = reinterpret_cast<uint16_t*>(smem);
@@ -615,10 +622,11 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
         const uint8_t* above = cls + (cell - (uint32_t)pw - 1u);
         const uint32_t vnw = above[0], vn = above[1], vne = above[2], vw = cls[cell - 1u];
         const bool n_ = vn == c, w_ = vw == c, nw = vnw == c, ne = vne == c;
-        // bits 26-28: 0 self, 1 N, 2 W, 3 NW, 4 NE
-        const uint32_t dir = n_ ? 1u : w_ ? 2u : nw ? 3u : ne ? 4u : 0u;
-        if (valid) keep[t] |= dir << 26;
+        // bits 26-28, the link as (rows up) << 2 | (columns right + 1): self 1, N 5, W 0, NW 4, NE 6
+        const uint32_t dir = n_ ? 5u : w_ ? 0u : nw ? 4u : ne ? 6u : 1u;
+        keep[t] |= valid ? dir << 26 : 0u;
         const bool join = !n_ & (w_ | nw) & ne;
+        if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two pixels' reads in flight, not all
         if (join) {
             const int at = atomicAdd(&s_joins, 1);
             if (at < JOINS)
@@ -633,10 +641,9 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     for (int t = 0; t < NPT; ++t)
         if (keep[t] != 0xffffffffu) {
             const uint32_t cell = keep[t] & 0xffffu, dir = (keep[t] >> 26) & 7u;
-            const uint32_t link = dir == 1u ? cell - pw : dir == 2u ? cell - 1 : dir == 3u ? cell - pw - 1
-                                                        : dir == 4u ? cell - pw + 1 : cell;
-            par[cell] = (uint16_t)link;
+            par[cell] = (uint16_t)(cell + (dir & 3u) - 1u - __umul24(dir >> 2, (uint32_t)pw));
         }
+    if (tid == 0) par[0] = 0;                              // (a border cell: where threads without a pixel point)
     __syncthreads();
     TIER_MARK(12)
     for (int e = tid, ne_ = min(s_joins, JOINS); e < ne_; e += THREADS) {
@@ -655,14 +662,33 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     TIER_MARK(13)
     // roots into registers (bit 24: this cell is a root), then the parent grid turns into 16-bit
     // size counters (two per word; a segment has < 65536 pixels, so no carry)
+    // Pointer jumping, all of a thread's pixels a step at a time: every pass replaces a pixel's pointer
+    // by that pointer's own and leaves it in the grid for the others (whatever a racing read sees is
+    // an ancestor), so the distances to the roots halve and a few passes of NPT reads in flight do
+    // what NPT walks of dependent reads did one after the other.  Pointers only ever decrease.
+    {
+        uint32_t p[NPT];
 #pragma unroll
-    for (int t = 0; t < NPT; ++t)
-        if (keep[t] != 0xffffffffu) {
-            const uint32_t cell = keep[t] & 0xffffu;
-            const uint32_t root = find16(par, cell);
-            par[cell] = (uint16_t)root;                    // shortens the walks of later cells
-            keep[t] = root | (keep[t] & 0xff0000u) | (root == cell ? 0x1000000u : 0u);
+        for (int t = 0; t < NPT; ++t) p[t] = par[keep[t] != 0xffffffffu ? keep[t] & 0xffffu : 0u];
+        while (true) {
+            bool moved = false;
+#pragma unroll
+            for (int t = 0; t < NPT; ++t) {
+                const uint32_t g = par[p[t]];
+                moved |= g != p[t];
+                p[t] = g;
+            }
+            if (!moved) break;
+#pragma unroll
+            for (int t = 0; t < NPT; ++t) par[keep[t] != 0xffffffffu ? keep[t] & 0xffffu : 0u] = (uint16_t)p[t];
         }
+#pragma unroll
+        for (int t = 0; t < NPT; ++t)
+            if (keep[t] != 0xffffffffu) {
+                const uint32_t cell = keep[t] & 0xffffu, root = p[t];
+                keep[t] = root | (keep[t] & 0xff0000u) | (root == cell ? 0x1000000u : 0u);
+            }
+    }
     __syncthreads();
     TIER_MARK(14)
     for (int i = tid; i < (area + 1) / 2; i += THREADS) reinterpret_cast<uint32_t*>(par)[i] = 0;
