@@ -662,33 +662,18 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     TIER_MARK(13)
     // roots into registers (bit 24: this cell is a root), then the parent grid turns into 16-bit
     // size counters (two per word; a segment has < 65536 pixels, so no carry)
-    // Pointer jumping, all of a thread's pixels a step at a time: every pass replaces a pixel's pointer
-    // by that pointer's own and leaves it in the grid for the others (whatever a racing read sees is
-    // an ancestor), so the distances to the roots halve and a few passes of NPT reads in flight do
-    // what NPT walks of dependent reads did one after the other.  Pointers only ever decrease.
-    {
-        uint32_t p[NPT];
+    // (Pointer jumping with all of a thread's pixels a step at a time -- NPT reads in flight instead of
+    // NPT walks of dependent reads -- was measured slower: waves do not run in step, so a wave's
+    // pointers advance one cell at a time through the cells of waves that have not got there yet;
+    // with a block barrier per pass slower still.)
 #pragma unroll
-        for (int t = 0; t < NPT; ++t) p[t] = par[keep[t] != 0xffffffffu ? keep[t] & 0xffffu : 0u];
-        while (true) {
-            bool moved = false;
-#pragma unroll
-            for (int t = 0; t < NPT; ++t) {
-                const uint32_t g = par[p[t]];
-                moved |= g != p[t];
-                p[t] = g;
-            }
-            if (!moved) break;
-#pragma unroll
-            for (int t = 0; t < NPT; ++t) par[keep[t] != 0xffffffffu ? keep[t] & 0xffffu : 0u] = (uint16_t)p[t];
+    for (int t = 0; t < NPT; ++t)
+        if (keep[t] != 0xffffffffu) {
+            const uint32_t cell = keep[t] & 0xffffu;
+            const uint32_t root = find16(par, cell);
+            par[cell] = (uint16_t)root;                    // shortens the walks of later cells
+            keep[t] = root | (keep[t] & 0xff0000u) | (root == cell ? 0x1000000u : 0u);
         }
-#pragma unroll
-        for (int t = 0; t < NPT; ++t)
-            if (keep[t] != 0xffffffffu) {
-                const uint32_t cell = keep[t] & 0xffffu, root = p[t];
-                keep[t] = root | (keep[t] & 0xff0000u) | (root == cell ? 0x1000000u : 0u);
-            }
-    }
     __syncthreads();
     TIER_MARK(14)
     for (int i = tid; i < (area + 1) / 2; i += THREADS) reinterpret_cast<uint32_t*>(par)[i] = 0;
