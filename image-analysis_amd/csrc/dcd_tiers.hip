@@ -475,7 +475,13 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
                     seen1 = tot;
                 }
             }
-            nj = (uint32_t)__shfl((int)field, lane & ~(GL - 1));   // the cluster's count
+            // the cluster's count = `field` of the first lane of its group of GL lanes, by DPP (a shuffle
+            // is an LDS round trip on the serial path of every round)
+            {
+                const int q0 = __builtin_amdgcn_mov_dpp((int)field, 0x00, 0xf, 0xf, true);       // quad_perm [0,0,0,0]
+                const int up4 = __builtin_amdgcn_update_dpp(0, q0, 0x114, 0xf, 0xf, true);       // row_shr:4
+                nj = (uint32_t)(GL == 8 && (lane & 4) ? up4 : q0);
+            }
             const unsigned long long empty = __ballot(cj < k && (lane & (GL - 1)) == 0 && nj == 0);
             if (empty == 0ull) {
                 update(wc);
