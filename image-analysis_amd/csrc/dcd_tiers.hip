@@ -19,8 +19,13 @@
 //     folding and updating for itself saved the second barrier but cost 8 x 200 vector
 //     instructions per round in a kernel whose vector pipe is the busiest unit (90 % by
 //     SQ_ACTIVE_INST_VALU): measured 3.77 -> 3.63 ms per stage at 64 images with the fold on one
-//     wave.  (Packed fp32 for the distances, two clusters per instruction, measured no gain:
-//     a v_pk_* takes the issue time of the two plain operations it replaces.)
+//     wave.
+//   * the distances of a round in expanded, centred form, two clusters per v_pk_fma_f32 with a
+//     scalar register pair for the centres' side, and a per-entry margin that sends near ties to
+//     the literal rule (comment at the rounds): 12 packed instructions per entry instead of 48
+//     plain ones, 12.95 -> 12.5 ms per call at 256 images.  (Packed fp32 on the subtract form had
+//     measured no gain: a v_pk_* takes the issue time of the two plain operations it replaces --
+//     unless those carry a scalar operand, which doubles theirs and not the packed one's.)
 //   * no calls and no second body: an empty cluster is re-seeded by the whole block in line (the
 //     mask is the same in every wave, so the branch is uniform over the block), and a segment
 //     whose colours overflow the table is put on the next tier's list (larger table) -- the last
@@ -33,7 +38,8 @@
 // note describes; the chain costs about 3 % of a segment.
 //
 // Arithmetic is the reference's, as in dcd_seg.hip: float32 distance sqrt((d0^2+d1^2)+d2^2) with a
-// strict '<' (evaluated literally only when two squared distances are within 2^-15 of each other),
+// strict '<' (evaluated literally only when an entry's two smallest keys are within the error margin of
+// the expanded form, see the rounds),
 // integer sums, float32 centre = sum / count, float32 shift sums added in float64.
 #include "common.h"
 #include "../../include/imgan.h"
@@ -69,6 +75,13 @@ __device__ volatile unsigned* tier_progress;
 #define TIER_MARK(i)
 #endif
 
+#ifdef IMGAN_TIE_COUNTS
+// how often the expanded distances hand an entry to the exact rule (never built into the product):
+// [0] wave trips, [1] trips with a hand-over, [2] entries, [3] handed over, [4] of those with equal keys,
+// [5] handed over in a segment's first round
+__device__ unsigned long long tie_counts[8];
+#endif
+
 struct TierArgs {
     const uint8_t* lab;
     int B, H, W, nseg, k, use_hash;
@@ -83,19 +96,40 @@ struct TierArgs {
     int tier, next_tier;                // list this launch works through / list for table overflows
 };
 
+// bytes behind the 64-bit slots: flags, centres, expanded centres
+#define TIER_TAIL(km) ((size_t)128 + (size_t)(km) * 32)
+
 // lanes that share an accumulator word (LDS atomics): a buffer is 1024 words either way
 __host__ __device__ constexpr int tier_copies(int km) { return 256 / km; }
 
 __host__ __device__ constexpr size_t tier_lds_bytes(int km, int cap) {
     // table + counts + colour indices (6 B per pixel of capacity), two accumulator buffers,
-    // the 64-bit slots, 16 words of flags
-    // the centres of the round (3 km floats)
-    return (size_t)cap * 6 + (size_t)2 * km * 4 * tier_copies(km) * 4 + (size_t)km * 8 + 64 +
-           (size_t)km * 3 * 4;
+    // the 64-bit slots, 32 words of flags, the centres of the round (km float4) and their
+    // expanded form (4 km floats: -2 c', |c'|^2)
+    return (size_t)cap * 6 + (size_t)2 * km * 4 * tier_copies(km) * 4 + (size_t)km * 8 + TIER_TAIL(km);
 }
 
 constexpr int tier_waves_per_simd(int km, int cap, int threads) {
     return (threads / 256) * (int)((160 * 1024) / tier_lds_bytes(km, cap));
+}
+
+// plain v_min_f32 / v_med3_f32 (the builtins come with a canonicalising instruction each)
+__device__ __forceinline__ float fmin2(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fmed3(float a, float b, float c) {
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// the cluster index in the low mantissa bits of a key: (t & ~(KM - 1)) | j, one v_and_or_b32 (the same
+// as a v_bitop3_b32 with both constants in line, a 2-cycle instruction on paper, was measured slower)
+template <int KM>
+__device__ __forceinline__ float with_index(float t, int j) {
+    return __uint_as_float((__float_as_uint(t) & ~(uint32_t)(KM - 1)) | (uint32_t)j);
 }
 
 __device__ __forceinline__ float lane_f(float v, int j) {
@@ -127,7 +161,9 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     uint32_t* acc = reinterpret_cast<uint32_t*>(smem + (size_t)CAP * 6);
     unsigned long long* slots = reinterpret_cast<unsigned long long*>(acc + 2 * BUF);
     int* flags = reinterpret_cast<int*>(slots + KM);
-    float* cen = reinterpret_cast<float*>(flags + 16);      // [cluster][component], written by wave 0
+    float* cen4 = reinterpret_cast<float*>(flags + 32);     // [cluster][component, 4th unused], written by wave 0
+    float* cenx = cen4 + KM * 4;                           // [-2 c'0, -2 c'1, -2 c'2, |c'|^2][cluster]
+    float* fflags = reinterpret_cast<float*>(flags);       // [8..10] centring point g, [11..12] the round's tie margin
     int& s_round = flags[5];                               // bit 0: stop, bit 1: a cluster ran empty
     int& s_full = flags[0];
     int& s_unique = flags[1];                              // ([2]: the ticket)
@@ -342,8 +378,41 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     const bool comp = cf >= 1 && cj < k && (lane & (FL - 1)) == 0;   // holds a centre component
     // lane that owns entry (cj, cf - 1) of the centres in LDS
     const bool holds = cf >= 1 && (lane & (FL - 1)) == 0;
-    float wc = 1.0e18f, wo = 0.f;                          // unused slots: far from every 8-bit colour,
-    if (wave == 0) {                                       // so the loop over all KM never picks them
+    float wc = 1.0e18f, wo = 0.f;                          // (unused clusters: never the nearest)
+    float gl = 0.f;                                        // wave 0: the centring point g in this lane's component
+    // the tie margin's coefficients (see the rounds), in units of 2^-24
+    constexpr float TIE_UNIT = 5.9604644775390625e-08f;
+    constexpr float TIE_U1 = KM == 8 ? 52.f : 86.f, TIE_U2 = 32.f;
+    // wave 0: the centres of the next round, as they are (for the exact replay) and expanded, and
+    // the coefficients of the round's tie margin (see the rounds)
+    auto publish = [&]() {
+        const float cp = __fsub_rn(wc, gl);                // the centred component c' (on `comp` lanes)
+        float sq = comp ? __fmul_rn(cp, cp) : 0.f;         // |c'|^2 over the cluster's GL lanes
+        sq = __fadd_rn(sq, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0xb1, 0xf, 0xf, true)));
+        sq = __fadd_rn(sq, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0x4e, 0xf, 0xf, true)));
+        if (GL == 8)
+            sq = __fadd_rn(sq, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0x141, 0xf, 0xf, true)));
+        const bool head = cf == 0 && (lane & (FL - 1)) == 0;         // the lane that holds |c'_j|^2
+        const float word = cf == 0 ? (cj < k ? sq : 3.0e38f) : (comp ? -2.f * cp : 0.f);
+        if ((lane & (FL - 1)) == 0) cenx[(cf == 0 ? 3 : cf - 1) * KM + cj] = word;
+        if (holds) cen4[cj * 4 + (cf - 1)] = wc;
+        // C2 = the largest |c'_j|^2 (non-negative floats order as integers)
+        uint32_t c2 = head && cj < k ? __float_as_uint(sq) : 0u;
+#define ROW_MAX(ctrl) c2 = max(c2, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c2, ctrl, 0xf, 0xf, true));
+        ROW_MAX(0xb1) ROW_MAX(0x4e) ROW_MAX(0x141) ROW_MAX(0x140)
+#undef ROW_MAX
+        const uint32_t c2u = max(max((uint32_t)__builtin_amdgcn_readlane((int)c2, 0), (uint32_t)__builtin_amdgcn_readlane((int)c2, 16)),
+                                 max((uint32_t)__builtin_amdgcn_readlane((int)c2, 32), (uint32_t)__builtin_amdgcn_readlane((int)c2, 48)));
+        const float C2 = __uint_as_float(c2u);
+        if (lane == 0) {
+            // centres too large for the expanded form (a caller's initial centres): no margin, every entry
+            // of the round takes the exact rule
+            const bool sane = C2 < 1.0e30f;
+            fflags[11] = sane ? (TIE_U1 + TIE_U2) * TIE_UNIT * C2 + 1.0e-30f : __builtin_nanf("");
+            fflags[12] = 2.002f * TIE_U1 * TIE_UNIT * __builtin_amdgcn_sqrtf(C2);
+        }
+    };
+    if (wave == 0) {
         const int j = cj < k ? cj : 0, f = cf >= 1 ? cf - 1 : 0;
         float v0;
         if (A.use_hash) {
@@ -355,15 +424,27 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             v0 = A.centres[((size_t)gs * k + j) * 3 + f];
         }
         if (comp) wc = v0;
-        if (holds) cen[cj * 3 + (cf - 1)] = wc;
+        // The centring point g of the expanded distances: the mean of the initial centres, rounded to
+        // integers (pixels of the segment drawn at random: close to its mean colour).  Any integers do
+        // for the results; how small |f - g| and |c - g| are decides how rarely the exact rule is called.
+        if (holds) cen4[cj * 4 + (cf - 1)] = wc;           // (LDS operations of a wave stay in order)
+        {
+            float sum = 0.f;
+            for (int q = 0; q < k; ++q) sum += cen4[q * 4 + (cf >= 1 ? cf - 1 : 0)];
+            gl = rintf(fminf(fmaxf(sum / (float)k, 0.f), 255.f));
+            if (holds && cj == 0) fflags[8 + (cf - 1)] = gl;
+        }
+        publish();
     }
     __syncthreads();
+    // the centring point, the same in every lane of the block
+    const float g0s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fflags[8])));
+    const float g1s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fflags[9])));
+    const float g2s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(fflags[10])));
     double old_sum = 0.0;
     int rounds = 0;
     uint32_t field = 0;                                    // lane (j, f): field f of cluster j, last round
     uint32_t seen0 = 0, seen1 = 0;                         // this lane's running totals of the two buffers
-    // a q within 2^-15 of the smallest one replays the literal rule (margins as in dcd_seg.hip)
-    const float NEAR = 1.0f - 3.0517578125e-05f;
     constexpr uint32_t IDXM = KM - 1;
     // The accumulators are never cleared: two buffers take the rounds in turn (nothing adds to a
     // buffer while a wave may still be reading it: round r adds before barrier r, round r + 2
@@ -371,51 +452,118 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     // sums are the buffer's totals minus the totals this lane saw two rounds ago (mod 2^32).
     int buf = 0;
     const int copy = lane & (COPIES - 1);
+    // The distances of a round in expanded form.  With g a fixed point near the segment's mean colour
+    // (integers), f' = f - g (exact) and c' = c - g:
+    //     |f - c|^2 - |f'|^2 = |c'|^2 - 2 c'0 f'0 - 2 c'1 f'1 - 2 c'2 f'2 =: t
+    // -- three fused multiply-adds per cluster instead of three subtracts, a multiply and two of them,
+    // and two clusters per v_pk_fma_f32 with the centres' side in a scalar register pair (measured,
+    // tools/issue_rate.hip: 4 cycles for the pair; the subtract form is 12 cycles per cluster, its
+    // operations with a scalar operand being 4-cycle ones).  |f'|^2 is the same for every cluster of an
+    // entry, so the order of the t is the order of the squared distances; t may be negative, the keys
+    // are compared as floats.  What the form costs is precision, and the margin pays for it.  With
+    // C2 = the largest |c'_j|^2 of the round and S1 = |f'0| + |f'1| + |f'2| >= |f'|, every value met on
+    // the way to a key is at most M = C2 + 2 sqrt(C2) S1 in magnitude, so a key differs from its exact
+    // value by at most (2 [c' rounded] + 2.5 [|c'|^2] + 3 [the chain] + 2 KM [index in the low mantissa
+    // bits: 8 or 16 ulp]) 2^-24 M, and the literal rule (float32 sqrt of a float32 sum of squares,
+    // strict '<') follows the exact order whenever two exact q differ by more than 14 x 2^-24 of the
+    // larger, which is at most 2 S1^2 + 2 C2.  An entry whose two smallest keys are closer than
+    //     margin = A + B S1 + D S1^2,  A = (U1 + 32) 2^-24 C2,  B = 2 U1 2^-24 sqrt(C2),  D = 32 x 2^-24
+    // (U1 = 52 for 8 clusters, 86 for 16: the sums above come to 47 and 79 for the two keys; a key
+    // further up only gains on its own error) is assigned by the literal rule instead, evaluated for
+    // the clusters whose keys lie within that margin of the smallest: every other cluster is farther
+    // by the literal rule too.  The margin is a few thousandths for a superpixel of one colour mode
+    // and a tenth for one that straddles two (colours and centres 50 and more from g); nothing here
+    // depends on g but how often the literal rule is called.  On the bench batch 0.28 % of the
+    // entries go there, nearly all of them true ties (clusters with one and the same centre, which
+    // the subtract form sent there as well): tighter margins from |f'|^2 and the keys themselves
+    // (0.27 %) cost more per entry than they saved.
+    typedef float float2v __attribute__((ext_vector_type(2)));
     while (true) {
-        float c0[KM], c1[KM], c2[KM];                      // scalars: the same in every lane
+        float2v m0[KM / 2], m1[KM / 2], m2[KM / 2], cc[KM / 2];   // m: scalars, the same in every lane
         {
-            const float cv = cen[lane < KM * 3 ? lane : 0];
+            const float cv = cenx[lane & (3 * KM <= 32 ? 31 : 63)];
 #pragma unroll
-            for (int j = 0; j < KM; ++j) {
-                c0[j] = lane_f(cv, 3 * j);
-                c1[j] = lane_f(cv, 3 * j + 1);
-                c2[j] = lane_f(cv, 3 * j + 2);
+            for (int jp = 0; jp < KM / 2; ++jp) {
+                m0[jp] = float2v{lane_f(cv, 2 * jp), lane_f(cv, 2 * jp + 1)};
+                m1[jp] = float2v{lane_f(cv, KM + 2 * jp), lane_f(cv, KM + 2 * jp + 1)};
+                m2[jp] = float2v{lane_f(cv, 2 * KM + 2 * jp), lane_f(cv, 2 * KM + 2 * jp + 1)};
+                cc[jp] = *reinterpret_cast<const float2v*>(cenx + 3 * KM + 2 * jp);   // one address for the wave
             }
         }
+        // the margin's coefficients, the same in every lane (vector registers: two scalar operands do
+        // not fit one instruction)
+        const float tolA = fflags[11], tolB = fflags[12];
+        float tolD = TIE_U2 * TIE_UNIT;
+        asm("" : "+v"(tolD));
         uint32_t* ab = acc + buf * BUF + copy;
         for (int i = tid; i < nloop; i += THREADS) {
             const uint32_t v = tab[i];
             const uint32_t weight = (uint32_t)ucnt[i];
             const uint32_t u0 = v & 255u, u1 = (v >> 8) & 255u, u2 = (v >> 16) & 255u;
-            const float f0 = (float)u0, f1 = (float)u1, f2 = (float)u2;
-            // the first minimum of sqrt_rn(q) is the first minimum of q unless another q lies
-            // within a few ulp of the smallest: track the two smallest q (cluster index in the low
-            // mantissa bits), replay the literal rule on a near tie
-            uint32_t best = 0xffffffffu, second = 0xffffffffu;
+            const float f0 = (float)u0 - g0s, f1 = (float)u1 - g1s, f2 = (float)u2 - g2s;
+            const float2v F0 = float2v{f0, f0}, F1 = float2v{f1, f1}, F2 = float2v{f2, f2};
+            // the two smallest keys (cluster index in the low mantissa bits), compared as floats
+            float best = __builtin_inff(), second = __builtin_inff();
 #pragma unroll
-            for (int j = 0; j < KM; ++j) {
-                const float d0 = f0 - c0[j], d1 = f1 - c1[j], d2 = f2 - c2[j];
-                const float q = __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, d0 * d0));
-                const uint32_t kq = (__float_as_uint(q) & ~IDXM) | (uint32_t)j;
-                second = umed3(kq, best, second);
-                best = min(best, kq);
+            for (int jp = 0; jp < KM / 2; ++jp) {
+                const float2v t = __builtin_elementwise_fma(
+                    F2, m2[jp], __builtin_elementwise_fma(F1, m1[jp], __builtin_elementwise_fma(F0, m0[jp], cc[jp])));
+                const float ka = with_index<KM>(t.x, 2 * jp);
+                second = fmed3(ka, best, second);
+                best = fmin2(best, ka);
+                const float kb = with_index<KM>(t.y, 2 * jp + 1);
+                second = fmed3(kb, best, second);
+                best = fmin2(best, kb);
             }
-            int bi = (int)(best & IDXM);
-            if (__builtin_expect(__fmul_rn(__uint_as_float(second), NEAR) < __uint_as_float(best), 0)) {
+            int bi = (int)(__float_as_uint(best) & IDXM);
+            const float s1 = (fabsf(f0) + fabsf(f1)) + fabsf(f2);
+            const float margin = __builtin_fmaf(s1, __builtin_fmaf(s1, tolD, tolB), tolA);
+#ifdef IMGAN_TIE_COUNTS
+            {
+                const bool hit = !(__fsub_rn(second, best) >= margin);
+                const bool zero = __fsub_rn(second, best) == 0.f;
+                const unsigned long long bh = __ballot(hit), bz = __ballot(zero), ba = __ballot(true);
+                if (lane == 0) {
+                    atomicAdd(&tie_counts[0], 1ull);
+                    atomicAdd(&tie_counts[1], bh != 0ull ? 1ull : 0ull);
+                    atomicAdd(&tie_counts[2], (unsigned long long)__popcll(ba));
+                    atomicAdd(&tie_counts[3], (unsigned long long)__popcll(bh));
+                    atomicAdd(&tie_counts[4], (unsigned long long)__popcll(bz));
+                    atomicAdd(&tie_counts[5], rounds == 0 ? (unsigned long long)__popcll(bh) : 0ull);
+                }
+            }
+#endif
+            // (negated: a margin that is not a number sends every entry to the exact rule)
+            if (__builtin_expect(!(__fsub_rn(second, best) >= margin), 0)) {
+                // ---- the literal rule (:88-91), in cluster order with a strict '<', over the clusters
+                // whose key is within the margin of the smallest: the others are farther by that rule too
+                uint32_t cold = 0;
+                asm volatile("" : "+v"(cold));             // (keeps the centre reads inside this block)
+                const float4* cq = reinterpret_cast<const float4*>(cen4 + cold);
+                const float l0 = (float)u0, l1 = (float)u1, l2 = (float)u2;
                 float bs = __builtin_inff();
                 bi = 0;
 #pragma unroll
-                for (int j = 0; j < KM; ++j)
-                    if (j < k) {
-                        const float e0 = __fsub_rn(f0, c0[j]), e1 = __fsub_rn(f1, c1[j]),
-                                    e2 = __fsub_rn(f2, c2[j]);
-                        const float sq = __fsqrt_rn(__fadd_rn(
-                            __fadd_rn(__fmul_rn(e0, e0), __fmul_rn(e1, e1)), __fmul_rn(e2, e2)));
-                        if (sq < bs) {
-                            bs = sq;
-                            bi = j;
+                for (int jp = 0; jp < KM / 2; ++jp) {
+                    const float2v t = __builtin_elementwise_fma(
+                        F2, m2[jp], __builtin_elementwise_fma(F1, m1[jp], __builtin_elementwise_fma(F0, m0[jp], cc[jp])));
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = 2 * jp + h;
+                        if (j >= k) continue;                          // (the same in every lane)
+                        const float kj = with_index<KM>(h ? t.y : t.x, j);
+                        if (!(__fsub_rn(kj, best) >= margin)) {
+                            const float4 c = cq[j];
+                            const float e0 = __fsub_rn(l0, c.x), e1 = __fsub_rn(l1, c.y), e2 = __fsub_rn(l2, c.z);
+                            const float sq = __fsqrt_rn(__fadd_rn(
+                                __fadd_rn(__fmul_rn(e0, e0), __fmul_rn(e1, e1)), __fmul_rn(e2, e2)));
+                            if (sq < bs) {
+                                bs = sq;
+                                bi = j;
+                            }
                         }
                     }
+                }
             }
             tab[i] = (v & 0xffffffu) | ((uint32_t)bi << 24);
             uint32_t* a4 = ab + bi * (4 * COPIES);
@@ -454,7 +602,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             const double cent_sum = ((double)sh0 + (double)sh1) + (double)sh2;
             rounds += 1;
             const int stop = (fabs(old_sum - cent_sum) < 0.1 || rounds >= A.max_rounds) ? 1 : 0;
-            if (holds) cen[cj * 3 + (cf - 1)] = wc;
+            publish();
             if (lane == 0) s_round = stop;
             old_sum = cent_sum;
             wo = wc;
@@ -712,8 +860,11 @@ void dcd_dedup_kernel(TierArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // the workgroups draw tickets for the entries of their list: segments differ in size and in
     // rounds by an order of magnitude, so a fixed split would leave a long tail
-    int* ticket = reinterpret_cast<int*>(smem + tier_lds_bytes(KM, CAP) - 64 - KM * 3 * 4) + 2;
+    int* ticket = reinterpret_cast<int*>(smem + tier_lds_bytes(KM, CAP) - TIER_TAIL(KM)) + 2;
     const int count = A.L.hdr[A.tier];
+#ifdef IMGAN_TIER_TIMING
+    const unsigned long long t_begin_ = wall_clock64();
+#endif
     while (true) {
         if (threadIdx.x == 0) *ticket = atomicAdd(&A.L.hdr[8 + A.tier], 1);
         __syncthreads();
@@ -724,6 +875,17 @@ void dcd_dedup_kernel(TierArgs A) {
         dedup_segment<KM, CAP, THREADS>(smem, A, gs);
         __syncthreads();
     }
+#ifdef IMGAN_TIER_TIMING
+    // when the workgroups of a launch start and end: [18 + 4 tier ..] = {~first start, last end, sum of
+    // the ends, workgroups} -- last end minus mean end is what the launch's tail costs per slot
+    if (threadIdx.x == 0) {
+        const unsigned long long t_end_ = wall_clock64();
+        atomicMax(&tier_timing[18 + A.tier * 4 + 0], ~t_begin_);
+        atomicMax(&tier_timing[18 + A.tier * 4 + 1], t_end_);
+        atomicAdd(&tier_timing[18 + A.tier * 4 + 2], t_end_);
+        atomicAdd(&tier_timing[18 + A.tier * 4 + 3], 1ull);
+    }
+#endif
 }
 
 template <int KM, int CAP, int THREADS>
@@ -741,6 +903,14 @@ int launch(const TierArgs& A, size_t nsegs, int per_cu, hipStream_t st) {
 #ifdef IMGAN_TIER_PROGRESS
 extern "C" int imgan_debug_tier_progress(unsigned* host_visible) {
     IMGAN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(tier_progress), &host_visible, sizeof(host_visible)));
+    return 0;
+}
+#endif
+
+#ifdef IMGAN_TIE_COUNTS
+extern "C" int imgan_debug_tie_counts(unsigned long long* out8) {
+    IMGAN_HIP(hipDeviceSynchronize());
+    IMGAN_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(tie_counts), 64));
     return 0;
 }
 #endif

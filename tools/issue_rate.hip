@@ -122,7 +122,12 @@ constexpr int CHAINS = 8, UNROLL = 16;
     X(107, "mix: v_min_i32 + v_min_i32 (pair)", "v_min_i32 %0, %0, %1\n v_max_i32 %0, %0, %2", V1) \
     X(108, "mix: v_add_u32 + v_add_u32 (pair)", "v_add_u32 %0, %0, %1\n v_xor_b32 %0, %0, %2", V1) \
     X(109, "mix: dot4,mad24,bitop3,med3,min,sub (six)", "v_dot4_u32_u8 %0, %0, %3, 0\n v_mad_i32_i24 %0, %0, %3, %1\n v_bitop3_b32 %0, %0, %1, %2 bitop3:0xea\n v_med3_i32 %0, %0, %1, %2\n v_min_i32 %0, %0, %1\n v_sub_u32 %0, %0, %2", V1) \
-    X(110, "mix: 3 fast + 1 slow (four)", "v_add_u32 %0, %0, %1\n v_xor_b32 %0, %0, %2\n v_sub_u32 %0, %0, %1\n v_min_i32 %0, %0, %2", V1)
+    X(110, "mix: 3 fast + 1 slow (four)", "v_add_u32 %0, %0, %1\n v_xor_b32 %0, %0, %2\n v_sub_u32 %0, %0, %1\n v_min_i32 %0, %0, %2", V1) \
+    X(111, "v_pk_fma_f32 (v2,s2,v2)", "v_pk_fma_f32 %0, %1, s[42:43], %0", V2)                   \
+    X(112, "v_pk_fma_f32 (v splat,s2,v2)", "v_pk_fma_f32 %0, %1, s[42:43], %0 op_sel_hi:[0,1,1]", V2) \
+    X(113, "v_pk_mul_f32 (v2,s2)", "v_pk_mul_f32 %0, %0, s[42:43]", V2)                           \
+    X(114, "mix: 3 pk_fma(s2) + 2 x (and_or, med3, min) (nine)", "v_pk_fma_f32 %1, %2, s[42:43], %1 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %1, %2, s[42:43], %1 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %1, %2, s[42:43], %1 op_sel_hi:[0,1,1]\n v_and_or_b32 %0, %0, %3, %4\n v_med3_u32 %0, %0, %3, %4\n v_min_u32 %0, %0, %3\n v_and_or_b32 %0, %0, %3, %4\n v_med3_u32 %0, %0, %3, %4\n v_min_u32 %0, %0, %3", V3) \
+    X(115, "mix: sub(s), mul, pk_add(s2), fma, fma, and_or, med3, min (eight)", "v_sub_f32 %0, %5, %0\n v_mul_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, s[42:43]\n v_fma_f32 %0, %3, %3, %0\n v_fma_f32 %0, %4, %4, %0\n v_and_or_b32 %0, %0, %3, %4\n v_med3_u32 %0, %0, %3, %4\n v_min_u32 %0, %0, %3", V3)
 
 template <int OP>
 __global__ void rate_kernel(uint32_t* out, long long* cycles, int iters, uint32_t sarg) {
@@ -147,6 +152,7 @@ __global__ void rate_kernel(uint32_t* out, long long* cycles, int iters, uint32_
 #define V1(txt) asm volatile(txt : "+v"(a[c]) : "v"(x), "v"(y), "s"(sv) : "vcc", "s40", "s41", "s44");
 #define V0(txt) asm volatile(txt : "+v"(a[c]) : "v"(x), "v"(y), "s"(sv));
 #define V2(txt) asm volatile(txt : "+v"(p[c]) : "v"(px), "v"(x), "v"(y) : "vcc");
+#define V3(txt) asm volatile(txt : "+v"(a[c]), "+v"(p[c]) : "v"(px), "v"(x), "v"(y), "s"(sv));
 #define X(id, name, txt, kind) if (OP == id) { kind(txt) }
                 OPS(X)
 #undef X
@@ -164,8 +170,11 @@ __global__ void rate_kernel(uint32_t* out, long long* cycles, int iters, uint32_
 static uint32_t* g_out;
 static long long *g_cyc, *g_host;
 
+static int g_first = 0;
+
 template <int OP>
 void run(const char* name, int per_step) {
+    if (OP < g_first) return;
     const int iters = 3000;
     int ncu = 0;
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
@@ -201,14 +210,15 @@ void run(const char* name, int per_step) {
     printf("\n");
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_first = atoi(argv[1]);       // first row to run
     hipMalloc(&g_out, 1024 * 1024 * 4);
     hipMalloc(&g_cyc, 1024 * 16 * 8);
     g_host = (long long*)malloc(1024 * 16 * 8);
     for (int i = 0; i < 40; ++i) rate_kernel<0><<<1024, 1024>>>(g_out, g_cyc, 3000, 3u);   // clocks up
     hipDeviceSynchronize();
     printf("ns = elapsed time per wave-instruction and SIMD; tk = s_memtime ticks of a wave per wave-instruction and SIMD\n");
-#define X(id, name, txt, kind) run<id>(name, (id == 47 || id == 48 || (id >= 106 && id <= 108)) ? 2 : id == 109 ? 6 : id == 110 ? 4 : 1);
+#define X(id, name, txt, kind) run<id>(name, (id == 47 || id == 48 || (id >= 106 && id <= 108)) ? 2 : id == 109 ? 6 : id == 110 ? 4 : id == 114 ? 9 : id == 115 ? 8 : 1);
     OPS(X)
 #undef X
     return 0;

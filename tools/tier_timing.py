@@ -27,5 +27,10 @@ tot = sum(buf[:len(names)])
 for n, v in zip(names, buf):
     print("%-24s %12d ticks  %5.1f%%  %6.2f us / segment" % (n, v, 100.0 * v / max(tot, 1), v / 100.0 / max(nseg, 1)))
 print("segments %d, per segment %.1f us of its workgroup's time (100 MHz clock)" % (nseg, tot / 100.0 / max(nseg, 1)))
+for t in range(3):
+    first, last, ends, wgs = ~buf[18 + 4 * t] & (2 ** 64 - 1), buf[19 + 4 * t], buf[20 + 4 * t], buf[21 + 4 * t]
+    if wgs:
+        print("tier %d: %4d workgroups, launch %.1f us, mean end %.1f us before the last one" %
+              (t, wgs, (last - first) / 100.0, (last - ends / wgs) / 100.0))
 rounds, _ = pipe.dcd.rounds()
 print("mean rounds per segment %.2f" % float(rounds.float().mean()))
