@@ -78,7 +78,8 @@ __device__ volatile unsigned* tier_progress;
 #ifdef IMGAN_TIE_COUNTS
 // how often the expanded distances hand an entry to the exact rule (never built into the product):
 // [0] wave trips, [1] trips with a hand-over, [2] entries, [3] handed over, [4] of those with equal keys,
-// [5] handed over in a segment's first round
+// [5] handed over in a segment's first round, [7] second round, [6] handed over with two candidates at
+// one literal distance
 __device__ unsigned long long tie_counts[8];
 #endif
 
@@ -385,7 +386,17 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     constexpr float TIE_U1 = KM == 8 ? 52.f : 86.f, TIE_U2 = 32.f;
     // wave 0: the centres of the next round, as they are (for the exact replay) and expanded, and
     // the coefficients of the round's tie margin (see the rounds)
-    auto publish = [&]() {
+    // `fresh`: the centres may all be colours of pixels (the initial centres are), i.e. integers.  Then
+    // every step of the expanded form is exact (integers below 2^20, whose low mantissa bits are free
+    // for the index), the literal rule is the order of the exact q with the lower index first among
+    // equals, and with a constant on top that makes every key positive the keys give exactly that:
+    // such a round needs no margin.  It matters: between integer centres a lattice of integer
+    // colours has many points at equal distance -- 2.8 % of the entries of a segment's first round on
+    // the bench batch, so that nine wave trips in ten of that round went through the literal rule.
+    auto publish = [&](bool fresh) {
+        if (holds) cen4[cj * 4 + (cf - 1)] = wc;           // (LDS operations of a wave stay in order)
+        const bool whole = fresh && __ballot(comp && !(wc == rintf(wc) && wc >= 0.f && wc <= 255.f)) == 0ull;
+        const float lift = whole ? 195076.f : 0.f;         // 3 x 255^2 + 1 >= |f'|^2 + 1
         const float cp = __fsub_rn(wc, gl);                // the centred component c' (on `comp` lanes)
         float sq = comp ? __fmul_rn(cp, cp) : 0.f;         // |c'|^2 over the cluster's GL lanes
         sq = __fadd_rn(sq, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0xb1, 0xf, 0xf, true)));
@@ -393,9 +404,8 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
         if (GL == 8)
             sq = __fadd_rn(sq, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), 0x141, 0xf, 0xf, true)));
         const bool head = cf == 0 && (lane & (FL - 1)) == 0;         // the lane that holds |c'_j|^2
-        const float word = cf == 0 ? (cj < k ? sq : 3.0e38f) : (comp ? -2.f * cp : 0.f);
+        const float word = cf == 0 ? (cj < k ? __fadd_rn(sq, lift) : 3.0e38f) : (comp ? -2.f * cp : 0.f);
         if ((lane & (FL - 1)) == 0) cenx[(cf == 0 ? 3 : cf - 1) * KM + cj] = word;
-        if (holds) cen4[cj * 4 + (cf - 1)] = wc;
         // C2 = the largest |c'_j|^2 (non-negative floats order as integers)
         uint32_t c2 = head && cj < k ? __float_as_uint(sq) : 0u;
 #define ROW_MAX(ctrl) c2 = max(c2, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c2, ctrl, 0xf, 0xf, true));
@@ -408,7 +418,8 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             // centres too large for the expanded form (a caller's initial centres): no margin, every entry
             // of the round takes the exact rule
             const bool sane = C2 < 1.0e30f;
-            fflags[11] = sane ? (TIE_U1 + TIE_U2) * TIE_UNIT * C2 + 1.0e-30f : __builtin_nanf("");
+            fflags[11] = whole ? -__builtin_inff()
+                         : sane ? (TIE_U1 + TIE_U2) * TIE_UNIT * C2 + 1.0e-30f : __builtin_nanf("");
             fflags[12] = 2.002f * TIE_U1 * TIE_UNIT * __builtin_amdgcn_sqrtf(C2);
         }
     };
@@ -434,7 +445,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             gl = rintf(fminf(fmaxf(sum / (float)k, 0.f), 255.f));
             if (holds && cj == 0) fflags[8 + (cf - 1)] = gl;
         }
-        publish();
+        publish(true);
     }
     __syncthreads();
     // the centring point, the same in every lane of the block
@@ -478,7 +489,13 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
     // the subtract form sent there as well): tighter margins from |f'|^2 and the keys themselves
     // (0.27 %) cost more per entry than they saved.
     typedef float float2v __attribute__((ext_vector_type(2)));
+#ifdef IMGAN_TIE_COUNTS
+    int rnd_ = -1;
+#endif
     while (true) {
+#ifdef IMGAN_TIE_COUNTS
+        ++rnd_;
+#endif
         float2v m0[KM / 2], m1[KM / 2], m2[KM / 2], cc[KM / 2];   // m: scalars, the same in every lane
         {
             const float cv = cenx[lane & (3 * KM <= 32 ? 31 : 63)];
@@ -529,7 +546,8 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
                     atomicAdd(&tie_counts[2], (unsigned long long)__popcll(ba));
                     atomicAdd(&tie_counts[3], (unsigned long long)__popcll(bh));
                     atomicAdd(&tie_counts[4], (unsigned long long)__popcll(bz));
-                    atomicAdd(&tie_counts[5], rounds == 0 ? (unsigned long long)__popcll(bh) : 0ull);
+                    atomicAdd(&tie_counts[5], rnd_ == 0 ? (unsigned long long)__popcll(bh) : 0ull);
+                    atomicAdd(&tie_counts[7], rnd_ == 1 ? (unsigned long long)__popcll(bh) : 0ull);
                 }
             }
 #endif
@@ -543,6 +561,9 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
                 const float l0 = (float)u0, l1 = (float)u1, l2 = (float)u2;
                 float bs = __builtin_inff();
                 bi = 0;
+#ifdef IMGAN_TIE_COUNTS
+                bool dupl_ = false;
+#endif
 #pragma unroll
                 for (int jp = 0; jp < KM / 2; ++jp) {
                     const float2v t = __builtin_elementwise_fma(
@@ -557,6 +578,10 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
                             const float e0 = __fsub_rn(l0, c.x), e1 = __fsub_rn(l1, c.y), e2 = __fsub_rn(l2, c.z);
                             const float sq = __fsqrt_rn(__fadd_rn(
                                 __fadd_rn(__fmul_rn(e0, e0), __fmul_rn(e1, e1)), __fmul_rn(e2, e2)));
+#ifdef IMGAN_TIE_COUNTS
+                            if (sq == bs) dupl_ = true;
+                            if (sq < bs) dupl_ = false;
+#endif
                             if (sq < bs) {
                                 bs = sq;
                                 bi = j;
@@ -564,6 +589,9 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
                         }
                     }
                 }
+#ifdef IMGAN_TIE_COUNTS
+                atomicAdd(&tie_counts[6], dupl_ ? 1ull : 0ull);
+#endif
             }
             tab[i] = (v & 0xffffffu) | ((uint32_t)bi << 24);
             uint32_t* a4 = ab + bi * (4 * COPIES);
@@ -578,7 +606,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
         uint32_t nj = 0;
         // centre update + stop rule (:93-107) on wave 0's lanes; leaves the new centres and the
         // decision in LDS
-        auto update = [&](float drawn) {
+        auto update = [&](float drawn, bool fresh) {
             // one division for all components
             float shift = 0.f;
             if (comp) {
@@ -602,7 +630,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             const double cent_sum = ((double)sh0 + (double)sh1) + (double)sh2;
             rounds += 1;
             const int stop = (fabs(old_sum - cent_sum) < 0.1 || rounds >= A.max_rounds) ? 1 : 0;
-            publish();
+            publish(fresh);
             if (lane == 0) s_round = stop;
             old_sum = cent_sum;
             wo = wc;
@@ -632,7 +660,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             }
             const unsigned long long empty = __ballot(cj < k && (lane & (GL - 1)) == 0 && nj == 0);
             if (empty == 0ull) {
-                update(wc);
+                update(wc, false);
             } else if (lane == 0) {
                 s_round = 2;
                 *reinterpret_cast<unsigned long long*>(&flags[6]) = empty;
@@ -668,7 +696,7 @@ __device__ __forceinline__ void dedup_segment(unsigned char* smem, const TierArg
             if (wave == 0) {
                 float drawn = wc;
                 if (comp && nj == 0) drawn = (float)A.lab[(img + (uint32_t)slots[cj]) * 3 + (cf - 1)];
-                update(drawn);
+                update(drawn, true);
             }
             __syncthreads();
             decision = *reinterpret_cast<volatile int*>(&s_round);

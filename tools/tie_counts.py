@@ -19,5 +19,5 @@ buf = (ctypes.c_ulonglong * 8)()
 lib.imgan_debug_tie_counts(buf)
 trips, hit_trips, entries, hits, zeros, first = buf[0], buf[1], buf[2], buf[3], buf[4], buf[5]
 print("wave trips %d, with a hand-over %d (%.2f%%)" % (trips, hit_trips, 100.0 * hit_trips / max(trips, 1)))
-print("entries %d, handed over %d (%.4f%%), with equal keys %d, in first rounds %d" %
-      (entries, hits, 100.0 * hits / max(entries, 1), zeros, first))
+print("entries %d, handed over %d (%.4f%%): %d in first rounds, %d in second rounds, %d with two candidates at one literal distance" %
+      (entries, hits, 100.0 * hits / max(entries, 1), first, buf[7], buf[6]))
