@@ -129,6 +129,53 @@ def test_listed_equals_gather_edge_cases():
     _same(a, b)
 
 
+@pytest.mark.parametrize("k", [4, 8, 12])
+def test_listed_equals_gather_with_a_callers_centres(k):
+    """The tier kernels compute the rounds' distances in expanded form around a centring point and
+    hand near ties to the literal rule by an error margin; the gather kernels subtract.  Initial
+    centres a caller may pass -- fractions, values far outside 0..255, absurdly large ones (no margin
+    holds: every entry takes the literal rule), copies of one another, all equal -- must give the
+    same centres, assignment, statistics and round counts on both."""
+    torch = _torch()
+    from imgan import ops
+    from oracle.color import bgr2lab_u8
+    H, W = 240, 320
+    img = voronoi_image(H, W, 40, seed=23, noise=16.0)
+    labf = bgr2lab_u8(img)
+    lab = torch.from_numpy(labf).cuda().unsqueeze(0)
+    slic = ops.SlicPlan(1, H, W, 24)
+    slic.run(lab, 20.0, 3)
+    dl = slic.labels
+    nseg = slic.n
+    rng = np.random.RandomState(4)
+    flat = labf.reshape(-1, 3).astype(np.float32)
+    lbl = dl[0].cpu().numpy().ravel()
+    cen0 = np.zeros((1, nseg, k, 3), dtype=np.float32)
+    for s in range(nseg):
+        idx = np.nonzero(lbl == s)[0]
+        if not len(idx):
+            continue
+        c = flat[rng.choice(idx, k, replace=len(idx) < k)].copy()
+        kind = s % 6
+        if kind == 0:
+            c += rng.uniform(-0.5, 0.5, size=c.shape).astype(np.float32)      # fractions
+        elif kind == 1:
+            c[0] = [300.5, -40.25, 128.0]                                        # outside the colour cube
+            c[1] += 1000.0
+        elif kind == 2:
+            c[k - 1] = [1.0e20, -3.0e25, 7.0e18]                                 # beyond any margin
+        elif kind == 3:
+            c[1:] = c[0]                                                         # all one colour
+        elif kind == 4:
+            c[k // 2] = c[0]                                                     # one copy
+            c[k - 1] += 0.25
+        cen0[0, s] = c
+    a = _run(ops, torch, lab, dl, nseg, k, False, cen0=cen0, seed=3)
+    b = _run(ops, torch, lab, dl, nseg, k, True, cen0=cen0, seed=3)
+    _same(a, b)
+    assert (a[3] > 1).any()
+
+
 def test_listed_with_wrong_counts_stays_in_bounds():
     """Counts that disagree with the label map (a caller's mistake) lose pixels, not memory
     safety: the call finishes and the segments whose counts were right are unaffected."""
