@@ -544,7 +544,7 @@ def main():
                      "in LDS, so the HBM traffic it must move is 15 B/px (4 labels in, 4 positions out, "
                      "4 positions + 3 colours in; traffic above that: partial lines of the sort pass and of the "
                      "colour gather) and the kernels are bound by the vector pipe (SQ_ACTIVE_INST_VALU x 4 / "
-                     "SIMDs / cycles = 0.88 on the small tier, profiles/r03_pmc_B64.txt)" % t_bar),
+                     "SIMDs / cycles = 0.79 on the small tier, profiles/r03_pmc_B64.txt)" % t_bar),
             "roofline_kernels": others,
             "dcd_segments_at_round_cap": pipe.segments_at_round_cap(),
             "dcd_segments_left_to_streaming_rounds": int(segments_left),
