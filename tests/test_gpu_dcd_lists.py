@@ -176,6 +176,43 @@ def test_listed_equals_gather_with_a_callers_centres(k):
     assert (a[3] > 1).any()
 
 
+@pytest.mark.parametrize("case", range(10))
+def test_listed_equals_gather_on_hard_colour_sets(case):
+    """Segments whose colours stress the error margin of the tiers' expanded distances: the full
+    colour cube, two far modes, a few levels (exact ties between integer centres), nearly flat,
+    gradients; block segments of 576 to 9216 pixels, k = 2..16, hash-sampled and fractional given
+    centres (tools/stress_expanded.py runs more of the same)."""
+    torch = _torch()
+    from imgan import ops
+    rng = np.random.RandomState(1000 + case)
+    H, W = 192, 256
+    yy, xx = np.mgrid[0:H, 0:W]
+    kind = case % 5
+    if kind == 0:
+        img = rng.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+    elif kind == 1:
+        m = ((xx // 7 + yy // 5) & 1).astype(np.float32)[..., None]
+        lo, hi = rng.randint(0, 60, 3), rng.randint(190, 256, 3)
+        img = np.clip(lo + m * (hi - lo) + rng.normal(0, 6, (H, W, 3)), 0, 255).astype(np.uint8)
+    elif kind == 2:
+        img = (rng.randint(0, 5, size=(H, W, 3)) * 60).astype(np.uint8)
+    elif kind == 3:
+        img = np.clip(128 + rng.normal(0, 1.2, (H, W, 3)), 0, 255).astype(np.uint8)
+    else:
+        g = (xx * 255 // W).astype(np.float32)
+        img = np.clip(np.stack([g, 255 - g, (yy * 255 // H)], -1) + rng.normal(0, 3, (H, W, 3)), 0, 255).astype(np.uint8)
+    cell = [24, 48, 64, 96][case % 4]
+    labels = ((np.arange(H)[:, None] // cell) * ((W + cell - 1) // cell) + (np.arange(W)[None, :] // cell)).astype(np.int32)
+    nseg = int(labels.max()) + 1
+    k = [2, 3, 5, 8, 8, 12, 16][case % 7]
+    lab = torch.from_numpy(img).cuda().unsqueeze(0)
+    dl = torch.from_numpy(labels).cuda().unsqueeze(0)
+    cen0 = rng.uniform(0, 255, size=(1, nseg, k, 3)).astype(np.float32) if case % 3 == 2 else None
+    a = _run(ops, torch, lab, dl, nseg, k, False, cen0=cen0, seed=7 + case)
+    b = _run(ops, torch, lab, dl, nseg, k, True, cen0=cen0, seed=7 + case)
+    _same(a, b)
+
+
 def test_listed_with_wrong_counts_stays_in_bounds():
     """Counts that disagree with the label map (a caller's mistake) lose pixels, not memory
     safety: the call finishes and the segments whose counts were right are unaffected."""
